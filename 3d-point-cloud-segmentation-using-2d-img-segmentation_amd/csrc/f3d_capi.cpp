@@ -1,0 +1,611 @@
+// C-ABI layer of libf3d_hip.so (see include/f3d.h): context, scratch arena, host-pointer
+// wrappers, and the tiny per-view host geometry.  No CPU fallback: every compute entry point
+// needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "f3d.h"
+#include "f3d_kernels.h"
+#include "f3d_math.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_COUNT };
+
+thread_local char g_create_err[512] = "";
+
+}  // namespace
+
+struct f3d_ctx {
+    int device;
+    hipStream_t stream;
+    char err[512];
+    void* slot[SLOT_COUNT];
+    size_t cap[SLOT_COUNT];
+    int* dev_err;                       // sticky device error word
+    unsigned long long* table;          // open-addressing set of the uv2pt vote
+    size_t table_slots;
+    int* filter_dev;                    // filter_classes lists longer than 8
+    unsigned long long* count_dev;
+};
+
+namespace {
+
+int fail(f3d_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define F3D_HIP(ctx, call)                                                                               \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? F3D_ERR_NOMEM : F3D_ERR_HIP,  \
+                                          "%s: %s", #call, hipGetErrorString(e_));                       \
+    } while (0)
+
+int ensure(f3d_ctx* ctx, int s, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->cap[s] < bytes) {
+        if (ctx->slot[s]) { F3D_HIP(ctx, hipFree(ctx->slot[s])); ctx->slot[s] = nullptr; ctx->cap[s] = 0; }
+        size_t want = bytes + bytes / 8;
+        F3D_HIP(ctx, hipMalloc(&ctx->slot[s], want));
+        ctx->cap[s] = want;
+    }
+    *out = ctx->slot[s];
+    return F3D_OK;
+}
+
+hipStream_t pick(f3d_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+int enter(f3d_ctx* ctx) {
+    if (!ctx) return fail(nullptr, F3D_ERR_INVALID, "null context");
+    ctx->err[0] = 0;
+    F3D_HIP(ctx, hipSetDevice(ctx->device));
+    return F3D_OK;
+}
+
+size_t xyz_bytes(f3d_dtype dt, int64_t n) { return (size_t)n * 3 * (dt == F3D_F64 ? 8 : 4); }
+
+int make_filter(f3d_ctx* ctx, const int32_t* filter, int nfilter, int ncols, bool cols_must_exist, hipStream_t s,
+                f3d_filter_args* fa) {
+    fa->nfilter = 0; fa->cls_dev = nullptr;
+    for (int k = 0; k < 8; ++k) fa->cls[k] = -1;
+    if (nfilter < 0 || nfilter > F3D_MAX_FILTER) return fail(ctx, F3D_ERR_INVALID, "nfilter %d out of range", nfilter);
+    if (nfilter == 0 || !filter) {
+        if (nfilter != 0) return fail(ctx, F3D_ERR_INVALID, "filter is NULL");
+        return F3D_OK;
+    }
+    for (int k = 0; k < nfilter; ++k) {
+        // votes[:, filter_classes] raises IndexError for a column that does not exist (voting.py:121)
+        if (cols_must_exist && (filter[k] >= ncols || filter[k] < -ncols))
+            return fail(ctx, F3D_ERR_INDEX, "filter class %d is out of bounds for %d vote columns", filter[k], ncols);
+    }
+    fa->nfilter = nfilter;
+    int32_t tmp[F3D_MAX_FILTER];
+    for (int k = 0; k < nfilter; ++k) tmp[k] = filter[k] < 0 ? filter[k] + ncols : filter[k];   // NumPy negative index
+    if (nfilter <= 8) {
+        for (int k = 0; k < nfilter; ++k) fa->cls[k] = tmp[k];
+    } else {
+        F3D_HIP(ctx, hipMemcpyAsync(ctx->filter_dev, tmp, sizeof(int32_t) * nfilter, hipMemcpyHostToDevice, s));
+        fa->cls_dev = ctx->filter_dev;
+    }
+    return F3D_OK;
+}
+
+int take_error(f3d_ctx* ctx, hipStream_t s) {
+    int e = 0;
+    F3D_HIP(ctx, hipMemcpyAsync(&e, ctx->dev_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    if (e) {
+        F3D_HIP(ctx, hipMemsetAsync(ctx->dev_err, 0, sizeof(int), s));
+        F3D_HIP(ctx, hipStreamSynchronize(s));
+        if (e & F3D_DEVERR_INDEX) return fail(ctx, F3D_ERR_INDEX, "index out of bounds (the reference raises IndexError at voting.py:98)");
+    }
+    return F3D_OK;
+}
+
+// ---- host geometry, mirrored operation for operation by oracle/np_ref.py::frustum_data ------
+void inv3(const double K[9], double o[9]) {
+    const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+    const double A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
+    const double D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
+    const double G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
+    const double det = (a * A + b * D) + c * G;
+    o[0] = A / det; o[1] = B / det; o[2] = C / det;
+    o[3] = D / det; o[4] = E / det; o[5] = F / det;
+    o[6] = G / det; o[7] = H / det; o[8] = I / det;
+}
+
+struct frustum { double eye[3], lookat[3], normal[4][3]; };
+
+void frustum_of(const double K[9], double w, double h, const double q[4], const double t[3], frustum* fr) {
+    double Ki[9];
+    inv3(K, Ki);
+    const double pix[6][3] = {{0, 0, 0}, {0, 0, 1}, {w, 0, 1}, {w, h, 1}, {0, h, 1}, {w / 2, h / 2, 1}};
+    double world[6][3];
+    for (int k = 0; k < 6; ++k) {
+        f3d_p3 c;
+        c.x = (Ki[0] * pix[k][0] + Ki[1] * pix[k][1]) + Ki[2] * pix[k][2];      // camera_utils.py:86
+        c.y = (Ki[3] * pix[k][0] + Ki[4] * pix[k][1]) + Ki[5] * pix[k][2];
+        c.z = (Ki[6] * pix[k][0] + Ki[7] * pix[k][1]) + Ki[8] * pix[k][2];
+        c.x = c.x / 1; c.y = c.y / 1; c.z = c.z / 1;                           // rescale = 1 (:111)
+        const f3d_p3 r = f3d_rotate(q, c);                                      // :128-129 (forward rotation)
+        world[k][0] = r.x + t[0]; world[k][1] = r.y + t[1]; world[k][2] = r.z + t[2];
+    }
+    for (int c = 0; c < 3; ++c) fr->eye[c] = world[0][c];
+    {                                                                           // lookat = unit(centre - eye) (:148-150)
+        const double v0 = world[5][0] - world[0][0], v1 = world[5][1] - world[0][1], v2 = world[5][2] - world[0][2];
+        const double nn = sqrt((v0 * v0 + v1 * v1) + v2 * v2);
+        fr->lookat[0] = v0 / nn; fr->lookat[1] = v1 / nn; fr->lookat[2] = v2 / nn;
+    }
+    for (int k = 0; k < 4; ++k) {                                               // camera_utils.py:163-170
+        const double* ca = world[1 + k];
+        const double* cb = world[1 + (k + 1) % 4];
+        const double a0 = ca[0] - world[0][0], a1 = ca[1] - world[0][1], a2 = ca[2] - world[0][2];
+        const double b0 = cb[0] - world[0][0], b1 = cb[1] - world[0][1], b2 = cb[2] - world[0][2];
+        const double n0 = a1 * b2 - a2 * b1, n1 = a2 * b0 - a0 * b2, n2 = a0 * b1 - a1 * b0;
+        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+        fr->normal[k][0] = n0 / nn; fr->normal[k][1] = n1 / nn; fr->normal[k][2] = n2 / nn;
+    }
+}
+
+int quat_inverse(const double q[4], double o[4]) {
+    const double ss = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    if (ss == 0.0) return F3D_ERR_ZERO_QUAT;
+    o[0] = q[0] / ss; o[1] = -q[1] / ss; o[2] = -q[2] / ss; o[3] = -q[3] / ss;
+    return F3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int f3d_version(void) { return F3D_VERSION; }
+
+f3d_ctx* f3d_ctx_create(int device) {
+    g_create_err[0] = 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        fail(nullptr, F3D_ERR_HIP, "no HIP device available (%s); libf3d_hip has no CPU fallback",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= count) { fail(nullptr, F3D_ERR_INVALID, "device %d out of range [0,%d)", device, count); return nullptr; }
+    f3d_ctx* ctx = (f3d_ctx*)calloc(1, sizeof(f3d_ctx));
+    if (!ctx) { fail(nullptr, F3D_ERR_NOMEM, "out of host memory"); return nullptr; }
+    ctx->device = device;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&ctx->dev_err, sizeof(int)) == hipSuccess &&
+              hipMalloc((void**)&ctx->filter_dev, sizeof(int32_t) * F3D_MAX_FILTER) == hipSuccess &&
+              hipMalloc((void**)&ctx->count_dev, sizeof(unsigned long long)) == hipSuccess &&
+              hipMemset(ctx->dev_err, 0, sizeof(int)) == hipSuccess;
+    if (!ok) {
+        fail(nullptr, F3D_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
+        f3d_ctx_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+void f3d_ctx_destroy(f3d_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int s = 0; s < SLOT_COUNT; ++s) if (ctx->slot[s]) (void)hipFree(ctx->slot[s]);
+    if (ctx->dev_err) (void)hipFree(ctx->dev_err);
+    if (ctx->table) (void)hipFree(ctx->table);
+    if (ctx->filter_dev) (void)hipFree(ctx->filter_dev);
+    if (ctx->count_dev) (void)hipFree(ctx->count_dev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+const char* f3d_last_error(const f3d_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+int f3d_ctx_synchronize(f3d_ctx* ctx) {
+    int rc = enter(ctx); if (rc) return rc;
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+void* f3d_ctx_stream(f3d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------
+// host geometry
+// ---------------------------------------------------------------------------------------------
+int f3d_quat_inverse(const double q[4], double o[4]) {
+    if (!q || !o) return F3D_ERR_INVALID;
+    return quat_inverse(q, o);
+}
+
+int f3d_frustum_data(const double K[9], double w, double h, const double* q, const double* t, int nviews,
+                     double* eyes, double* lookats, double* face_normals) {
+    if (!K || !q || !t || nviews < 0) return F3D_ERR_INVALID;
+    for (int v = 0; v < nviews; ++v) {
+        frustum fr;
+        frustum_of(K, w, h, q + 4 * v, t + 3 * v, &fr);
+        if (eyes) memcpy(eyes + 3 * v, fr.eye, sizeof fr.eye);
+        if (lookats) memcpy(lookats + 3 * v, fr.lookat, sizeof fr.lookat);
+        if (face_normals) memcpy(face_normals + 12 * v, fr.normal, sizeof fr.normal);
+    }
+    return F3D_OK;
+}
+
+int f3d_views_build(const double K[9], double w, double h, const double* q, const double* t, int nviews, double max_depth,
+                    f3d_view* out) {
+    if (!K || !q || !t || !out || nviews < 0) return F3D_ERR_INVALID;
+    for (int v = 0; v < nviews; ++v) {
+        f3d_view* vw = out + v;
+        memset(vw, 0, sizeof *vw);
+        memcpy(vw->K, K, sizeof vw->K);
+        const int rc = quat_inverse(q + 4 * v, vw->qinv);
+        if (rc) return rc;
+        memcpy(vw->t, t + 3 * v, sizeof vw->t);
+        frustum fr;
+        frustum_of(K, w, h, q + 4 * v, t + 3 * v, &fr);
+        for (int m = 0; m < 4; ++m) {                                           // fusion.py:254 (spoke origins = eye)
+            memcpy(vw->plane_pt[m], fr.eye, sizeof fr.eye);
+            memcpy(vw->plane_n[m], fr.normal[m], sizeof fr.normal[m]);
+        }
+        for (int c = 0; c < 3; ++c) {                                           // fusion.py:255-256
+            vw->plane_pt[4][c] = fr.eye[c] + max_depth * fr.lookat[c];
+            vw->plane_n[4][c] = -fr.lookat[c];
+        }
+        double l1max = 0.0;
+        for (int m = 0; m < F3D_NPLANES; ++m) {
+            vw->plane_off[m] = fma(vw->plane_n[m][0], vw->plane_pt[m][0],
+                               fma(vw->plane_n[m][1], vw->plane_pt[m][1], vw->plane_n[m][2] * vw->plane_pt[m][2]));
+            const double nl1 = fabs(vw->plane_n[m][0]) + fabs(vw->plane_n[m][1]) + fabs(vw->plane_n[m][2]);
+            const double l1 = (fabs(vw->plane_pt[m][0]) + fabs(vw->plane_pt[m][1]) + fabs(vw->plane_pt[m][2])) * (nl1 > 1 ? nl1 : 1);
+            if (l1 > l1max) l1max = l1;
+        }
+        // both the pre-cull value and the exact dot product are within ~12 eps * (|p|_1 + |pp|_1) of the
+        // real number n.(p - pp); 64 eps leaves a 5x margin (|n|_inf <= 1 for unit normals; non-unit
+        // normals are covered by the nl1 factor above and by cull_rel scaling below)
+        const double eps64 = 64.0 * 2.220446049250313e-16;
+        double nmax = 1.0;
+        for (int m = 0; m < F3D_NPLANES; ++m)
+            for (int c = 0; c < 3; ++c) if (fabs(vw->plane_n[m][c]) > nmax) nmax = fabs(vw->plane_n[m][c]);
+        vw->cull_rel = eps64 * nmax;
+        vw->cull_abs = eps64 * l1max + 1e-300;
+    }
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a1 rotate
+// ---------------------------------------------------------------------------------------------
+int f3d_rotate_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double q[4], double* out) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!xyz || !out)) || !q) return fail(ctx, F3D_ERR_INVALID, "rotate: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *din, *dout;
+    if ((rc = ensure(ctx, SLOT_XYZ, (size_t)n * 24, &din))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 24, &dout))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(din, xyz, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    F3D_HIP(ctx, f3d_launch_rotate((const double*)din, n, q, (double*)dout, ctx->stream));
+    F3D_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2 / a4 / single-view fused
+// ---------------------------------------------------------------------------------------------
+int f3d_project_view_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* view, int32_t* uv,
+                         uint8_t* inside, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !view || (!uv && !inside) || (n > 0 && !xyz)) return fail(ctx, F3D_ERR_INVALID, "project_view: bad arguments");
+    F3D_HIP(ctx, f3d_launch_project_view(xyz, dtype, n, *view, uv, inside, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_project_view_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const f3d_view* view, int32_t* uv, uint8_t* inside) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !view || (!uv && !inside) || (n > 0 && !xyz)) return fail(ctx, F3D_ERR_INVALID, "project_view: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *din, *duv = nullptr, *din_s = nullptr;
+    if ((rc = ensure(ctx, SLOT_XYZ, (size_t)n * 24, &din))) return rc;
+    if (uv && (rc = ensure(ctx, SLOT_OUT0, (size_t)n * 8, &duv))) return rc;
+    if (inside && (rc = ensure(ctx, SLOT_OUT1, (size_t)n, &din_s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(din, xyz, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    F3D_HIP(ctx, f3d_launch_project_view(din, F3D_F64, n, *view, (int32_t*)duv, (uint8_t*)din_s, ctx->stream));
+    if (uv) F3D_HIP(ctx, hipMemcpyAsync(uv, duv, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (inside) F3D_HIP(ctx, hipMemcpyAsync(inside, din_s, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+static int pose_view(f3d_ctx* ctx, const double K[9], const double q[4], const double t[3], f3d_view* vw) {
+    if (!K || !q || !t) return fail(ctx, F3D_ERR_INVALID, "points2pixel: NULL camera");
+    memset(vw, 0, sizeof *vw);
+    memcpy(vw->K, K, sizeof vw->K);
+    memcpy(vw->t, t, sizeof vw->t);
+    if (quat_inverse(q, vw->qinv)) return fail(ctx, F3D_ERR_ZERO_QUAT, "a zero quaternion cannot be inverted");
+    return F3D_OK;
+}
+
+int f3d_points2pixel_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const double K[9], const double q[4],
+                         const double t[3], int32_t* uv, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    f3d_view vw;
+    if ((rc = pose_view(ctx, K, q, t, &vw))) return rc;
+    if (n < 0 || !uv || (n > 0 && !xyz)) return fail(ctx, F3D_ERR_INVALID, "points2pixel: bad arguments");
+    F3D_HIP(ctx, f3d_launch_project_view(xyz, dtype, n, vw, uv, nullptr, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_points2pixel_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double K[9], const double q[4], const double t[3],
+                         int32_t* uv) {
+    int rc = enter(ctx); if (rc) return rc;
+    f3d_view vw;
+    if ((rc = pose_view(ctx, K, q, t, &vw))) return rc;
+    return f3d_project_view_f64(ctx, xyz, n, &vw, uv, nullptr);
+}
+
+int f3d_inside_polyhedra_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const double* plane_pts,
+                             const double* normals, int m, uint8_t* inside, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || m < 0 || !inside || (n > 0 && !xyz) || (m > 0 && (!plane_pts || !normals)))
+        return fail(ctx, F3D_ERR_INVALID, "inside_polyhedra: bad arguments");
+    hipStream_t s = pick(ctx, stream);
+    int done = 0;
+    do {                                                    // m == 0: every point is inside (signsum == 0 == len)
+        f3d_plane_args pa;
+        pa.m = (m - done) < F3D_PLANES_PER_LAUNCH ? (m - done) : F3D_PLANES_PER_LAUNCH;
+        pa.accumulate = done > 0;
+        memcpy(pa.pt, plane_pts + 3 * done, sizeof(double) * 3 * pa.m);
+        memcpy(pa.n, normals + 3 * done, sizeof(double) * 3 * pa.m);
+        F3D_HIP(ctx, f3d_launch_inside_polyhedra(xyz, dtype, n, pa, inside, s));
+        done += pa.m;
+    } while (done < m);
+    return F3D_OK;
+}
+
+int f3d_inside_polyhedra_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double* plane_pts, const double* normals, int m,
+                             uint8_t* inside) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !inside || (n > 0 && !xyz)) return fail(ctx, F3D_ERR_INVALID, "inside_polyhedra: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *din, *dout;
+    if ((rc = ensure(ctx, SLOT_XYZ, (size_t)n * 24, &din))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT1, (size_t)n, &dout))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(din, xyz, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = f3d_inside_polyhedra_dev(ctx, din, F3D_F64, n, plane_pts, normals, m, (uint8_t*)dout, ctx->stream))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(inside, dout, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused multi-view path
+// ---------------------------------------------------------------------------------------------
+int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                                const uint8_t* masks, int h, int w, int nclasses, const int32_t* filter, int nfilter,
+                                double threshold, int64_t* classes, uint16_t* votes_u16, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || nviews < 0 || h <= 0 || w <= 0 || nclasses < 0 || nclasses > 65534 || !classes ||
+        (n > 0 && !xyz) || (nviews > 0 && (!views_dev || !masks)))
+        return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: bad arguments");
+    if (nviews > 65535) return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: at most 65535 views");
+    hipStream_t s = pick(ctx, stream);
+    f3d_filter_args fa;
+    if ((rc = make_filter(ctx, filter, nfilter, nclasses + 1, true, s, &fa))) return rc;
+    F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, h, w, nclasses, fa, threshold, classes, votes_u16,
+                                 ctx->dev_err, 0, s));
+    return F3D_OK;
+}
+
+int f3d_take_device_error(f3d_ctx* ctx, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    return take_error(ctx, pick(ctx, stream));
+}
+
+int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views, int nviews,
+                            const uint8_t* masks, int h, int w, int nclasses, const int32_t* filter, int nfilter,
+                            double threshold, int64_t* classes, uint16_t* votes_u16) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || nviews < 0 || h <= 0 || w <= 0 || nclasses < 0 || !classes || (n > 0 && !xyz) || (nviews > 0 && (!views || !masks)))
+        return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: bad arguments");
+    if (n == 0) return F3D_OK;
+    const size_t mbytes = (size_t)nviews * h * w, ncols = (size_t)nclasses + 1;
+    void *dxyz, *dviews, *dmasks, *dcls, *dvotes = nullptr;
+    if ((rc = ensure(ctx, SLOT_XYZ, xyz_bytes(dtype, n), &dxyz))) return rc;
+    if ((rc = ensure(ctx, SLOT_VIEWS, sizeof(f3d_view) * (size_t)nviews, &dviews))) return rc;
+    if ((rc = ensure(ctx, SLOT_MASKS, mbytes, &dmasks))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 8, &dcls))) return rc;
+    if (votes_u16 && (rc = ensure(ctx, SLOT_OUT1, (size_t)n * ncols * 2, &dvotes))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dxyz, xyz, xyz_bytes(dtype, n), hipMemcpyHostToDevice, s));
+    if (nviews) {
+        F3D_HIP(ctx, hipMemcpyAsync(dviews, views, sizeof(f3d_view) * (size_t)nviews, hipMemcpyHostToDevice, s));
+        F3D_HIP(ctx, hipMemcpyAsync(dmasks, masks, mbytes, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = f3d_project_vote_argmax_dev(ctx, dxyz, dtype, n, (const f3d_view*)dviews, nviews, (const uint8_t*)dmasks, h, w,
+                                          nclasses, filter, nfilter, threshold, (int64_t*)dcls, (uint16_t*)dvotes, s)))
+        return rc;
+    if ((rc = take_error(ctx, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(classes, dcls, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (votes_u16) F3D_HIP(ctx, hipMemcpyAsync(votes_u16, dvotes, (size_t)n * ncols * 2, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7 vote, a8 segment
+// ---------------------------------------------------------------------------------------------
+static int ensure_table(f3d_ctx* ctx, int64_t hw) {
+    size_t want = 1024;
+    while (want < (size_t)hw * 2) want <<= 1;
+    if (ctx->table_slots < want) {
+        if (ctx->table) { F3D_HIP(ctx, hipFree(ctx->table)); ctx->table = nullptr; ctx->table_slots = 0; }
+        F3D_HIP(ctx, hipMalloc((void**)&ctx->table, want * sizeof(unsigned long long)));
+        ctx->table_slots = want;
+    }
+    return F3D_OK;
+}
+
+int f3d_vote_uv2pt_dev(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts,
+                       int ncols, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (hw < 0 || npts < 0 || ncols <= 0 || (hw > 0 && (!uv2pt || !mask || !votes)))
+        return fail(ctx, F3D_ERR_INVALID, "vote_uv2pt: bad arguments");
+    if (hw == 0) return F3D_OK;
+    if ((rc = ensure_table(ctx, hw))) return rc;              // grows only when a larger frame arrives
+    size_t slots = 1024;
+    while (slots < (size_t)hw * 2) slots <<= 1;
+    F3D_HIP(ctx, f3d_launch_vote_uv2pt(uv2pt, mask, hw, votes, npts, ncols, ctx->table, slots, ctx->dev_err, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_vote_uv2pt(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (hw < 0 || npts < 0 || ncols <= 0 || (hw > 0 && (!uv2pt || !mask || !votes)))
+        return fail(ctx, F3D_ERR_INVALID, "vote_uv2pt: bad arguments");
+    if (hw == 0) return F3D_OK;
+    const size_t vbytes = (size_t)npts * ncols * 8;
+    void *dlut, *dmask, *dvotes;
+    if ((rc = ensure(ctx, SLOT_AUX0, (size_t)hw * 4, &dlut))) return rc;
+    if ((rc = ensure(ctx, SLOT_AUX1, (size_t)hw, &dmask))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT1, vbytes, &dvotes))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dlut, uv2pt, (size_t)hw * 4, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dmask, mask, (size_t)hw, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dvotes, votes, vbytes, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_vote_uv2pt_dev(ctx, (const int32_t*)dlut, (const uint8_t*)dmask, hw, (double*)dvotes, npts, ncols, s))) return rc;
+    if ((rc = take_error(ctx, s))) return rc;                 // nothing was written in that case
+    F3D_HIP(ctx, hipMemcpyAsync(votes, dvotes, vbytes, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+int f3d_segment_votes_dev(f3d_ctx* ctx, const double* votes, int64_t npts, int ncols, int nclasses, double threshold,
+                          const int32_t* filter, int nfilter, int64_t* classes, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (npts < 0 || ncols <= 0 || (npts > 0 && (!votes || !classes))) return fail(ctx, F3D_ERR_INVALID, "segment_votes: bad arguments");
+    hipStream_t s = pick(ctx, stream);
+    f3d_filter_args fa;
+    if ((rc = make_filter(ctx, filter, nfilter, ncols, true, s, &fa))) return rc;
+    F3D_HIP(ctx, f3d_launch_segment_votes(votes, npts, ncols, nclasses, threshold, fa, classes, s));
+    return F3D_OK;
+}
+
+int f3d_segment_votes(f3d_ctx* ctx, const double* votes, int64_t npts, int ncols, int nclasses, double threshold,
+                      const int32_t* filter, int nfilter, int64_t* classes) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (npts < 0 || ncols <= 0 || (npts > 0 && (!votes || !classes))) return fail(ctx, F3D_ERR_INVALID, "segment_votes: bad arguments");
+    if (npts == 0) return F3D_OK;
+    const size_t vbytes = (size_t)npts * ncols * 8;
+    void *dvotes, *dcls;
+    if ((rc = ensure(ctx, SLOT_OUT1, vbytes, &dvotes))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)npts * 8, &dcls))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dvotes, votes, vbytes, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_segment_votes_dev(ctx, (const double*)dvotes, npts, ncols, nclasses, threshold, filter, nfilter, (int64_t*)dcls, s)))
+        return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(classes, dcls, (size_t)npts * 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a9 mask post-processing
+// ---------------------------------------------------------------------------------------------
+int f3d_sem_logits_to_mask_dev(f3d_ctx* ctx, const float* sem, int c, int64_t hw, float conf, int low_label, uint8_t* mask,
+                               void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (c <= 0 || c > 256 || hw < 0 || low_label < 0 || low_label > 255 || (hw > 0 && (!sem || !mask)))
+        return fail(ctx, F3D_ERR_INVALID, "sem_logits_to_mask: bad arguments (1 <= c <= 256)");
+    F3D_HIP(ctx, f3d_launch_sem_to_mask(sem, c, hw, conf, low_label, mask, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_sem_logits_to_mask(f3d_ctx* ctx, const float* sem, int c, int64_t hw, float conf, int low_label, uint8_t* mask) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (c <= 0 || hw < 0 || (hw > 0 && (!sem || !mask))) return fail(ctx, F3D_ERR_INVALID, "sem_logits_to_mask: bad arguments");
+    if (hw == 0) return F3D_OK;
+    void *dsem, *dmask;
+    if ((rc = ensure(ctx, SLOT_MASKS, (size_t)c * hw * 4, &dsem))) return rc;
+    if ((rc = ensure(ctx, SLOT_AUX1, (size_t)hw, &dmask))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dsem, sem, (size_t)c * hw * 4, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_sem_logits_to_mask_dev(ctx, (const float*)dsem, c, hw, conf, low_label, (uint8_t*)dmask, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(mask, dmask, (size_t)hw, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a10/a11 oriented boxes
+// ---------------------------------------------------------------------------------------------
+int f3d_points_in_obb_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_obb* boxes, int b,
+                          uint32_t* inside_bits, uint8_t* cooc, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || b < 0 || b > F3D_OBB_MAX_BOXES || (b > 0 && !boxes) || (n > 0 && !xyz) || (!inside_bits && !cooc))
+        return fail(ctx, F3D_ERR_INVALID, "points_in_obb: bad arguments (at most %d boxes per call)", F3D_OBB_MAX_BOXES);
+    if (b == 0) return F3D_OK;
+    hipStream_t s = pick(ctx, stream);
+    void* dboxes;
+    if ((rc = ensure(ctx, SLOT_VIEWS, sizeof(f3d_obb) * (size_t)b, &dboxes))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(dboxes, boxes, sizeof(f3d_obb) * (size_t)b, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, f3d_launch_points_in_obb(xyz, dtype, n, (const f3d_obb*)dboxes, b, inside_bits, cooc, s));
+    return F3D_OK;
+}
+
+int f3d_points_in_obb(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_obb* boxes, int b,
+                      uint32_t* inside_bits, uint8_t* cooc) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || b < 0 || (n > 0 && !xyz) || (!inside_bits && !cooc)) return fail(ctx, F3D_ERR_INVALID, "points_in_obb: bad arguments");
+    if (b == 0) return F3D_OK;
+    const size_t words = (size_t)(b + 31) / 32;
+    void *dxyz, *dbits = nullptr, *dcooc = nullptr;
+    if ((rc = ensure(ctx, SLOT_XYZ, xyz_bytes(dtype, n), &dxyz))) return rc;
+    if (inside_bits && (rc = ensure(ctx, SLOT_OUT1, (size_t)n * words * 4, &dbits))) return rc;
+    if (cooc && (rc = ensure(ctx, SLOT_AUX0, (size_t)b * b, &dcooc))) return rc;
+    hipStream_t s = ctx->stream;
+    if (n) F3D_HIP(ctx, hipMemcpyAsync(dxyz, xyz, xyz_bytes(dtype, n), hipMemcpyHostToDevice, s));
+    if (cooc && n == 0) F3D_HIP(ctx, hipMemsetAsync(dcooc, 0, (size_t)b * b, s));
+    if ((rc = f3d_points_in_obb_dev(ctx, dxyz, dtype, n, boxes, b, (uint32_t*)dbits, (uint8_t*)dcooc, s))) return rc;
+    if (inside_bits && n) F3D_HIP(ctx, hipMemcpyAsync(inside_bits, dbits, (size_t)n * words * 4, hipMemcpyDeviceToHost, s));
+    if (cooc) F3D_HIP(ctx, hipMemcpyAsync(cooc, dcooc, (size_t)b * b, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+int f3d_relabel_dev(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to, int64_t* count_dev, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || (n > 0 && !ids)) return fail(ctx, F3D_ERR_INVALID, "relabel: bad arguments");
+    hipStream_t s = pick(ctx, stream);
+    if (count_dev) F3D_HIP(ctx, hipMemsetAsync(count_dev, 0, 8, s));
+    F3D_HIP(ctx, f3d_launch_relabel(ids, n, from, to, (unsigned long long*)count_dev, s));
+    return F3D_OK;
+}
+
+int f3d_relabel(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to, int64_t* count) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || (n > 0 && !ids)) return fail(ctx, F3D_ERR_INVALID, "relabel: bad arguments");
+    if (count) *count = 0;
+    if (n == 0) return F3D_OK;
+    void* dids;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 8, &dids))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dids, ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_relabel_dev(ctx, (int64_t*)dids, n, from, to, (int64_t*)ctx->count_dev, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(ids, dids, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (count) F3D_HIP(ctx, hipMemcpyAsync(count, ctx->count_dev, 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Internal interface between the C-ABI layer (f3d_capi.cpp) and the kernels (f3d_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "f3d.h"
+
+#define F3D_DEVERR_INDEX 1                 // sticky device error bit: the reference would raise IndexError
+#define F3D_PLANES_PER_LAUNCH 16
+#define F3D_OBB_MAX_BOXES 4096
+
+struct f3d_plane_args {                    // by-value kernel argument of k_inside_polyhedra
+    int m;
+    int accumulate;                        // 1: AND into the existing `inside` bytes (chained launches)
+    double pt[F3D_PLANES_PER_LAUNCH][3];
+    double n[F3D_PLANES_PER_LAUNCH][3];
+};
+
+struct f3d_filter_args {                   // filter_classes of VotingSegmentation.segment
+    int nfilter;                           // 0 = no filter
+    int cls[8];                            // the list itself when nfilter <= 8 (unused slots = -1)
+    const int* cls_dev;                    // device copy of the list when nfilter > 8
+};
+
+hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], double* out, hipStream_t s);
+hipError_t f3d_launch_project_view(const void* xyz, int dtype, int64_t n, const f3d_view& vw, int32_t* uv, uint8_t* inside,
+                                   hipStream_t s);
+hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, const f3d_plane_args& pa, uint8_t* inside,
+                                       hipStream_t s);
+size_t f3d_fuse_lds_bytes(int mode, int nclasses);
+int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
+hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                           const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
+                           int64_t* classes, uint16_t* votes, int* err, int grid_blocks, hipStream_t s);
+hipError_t f3d_launch_segment_votes(const double* votes, int64_t npts, int ncols, int nclasses, double threshold,
+                                    const f3d_filter_args& flt, int64_t* classes, hipStream_t s);
+hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols,
+                                 unsigned long long* table, uint64_t table_slots, int* err, hipStream_t s);
+hipError_t f3d_launch_sem_to_mask(const float* sem, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s);
+hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, uint32_t* bits,
+                                    uint8_t* cooc, hipStream_t s);
+hipError_t f3d_launch_relabel(int64_t* ids, int64_t n, int64_t from, int64_t to, unsigned long long* count, hipStream_t s);

@@ -1,0 +1,591 @@
+// HIP kernels of libf3d_hip.so for gfx950 (MI355X, CDNA4).  Wave = 64 lanes.
+//
+// Everything here is fp64 VALU + memory work: there is no dense contraction on this path, so no
+// MFMA.  The kernels are organised for coalesced HBM streams, scalar-register (SGPR) residency of
+// the per-view camera records, LDS vote histograms and ≫256 workgroups per launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "f3d.h"
+#include "f3d_math.h"
+#include "f3d_kernels.h"
+
+#pragma clang fp contract(off)
+
+#define F3D_BLOCK 256
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ f3d_p3 load_point(const T* __restrict__ xyz, int64_t i) {
+    const T* p = xyz + 3 * i;
+    f3d_p3 r;
+    r.x = (double)p[0]; r.y = (double)p[1]; r.z = (double)p[2];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// a1: rotate
+// ------------------------------------------------------------------------------------------
+struct quat_arg { double q[4]; };
+
+__global__ __launch_bounds__(F3D_BLOCK) void k_rotate(const double* __restrict__ xyz, int64_t n,
+                                                       quat_arg qa, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const f3d_p3 o = f3d_rotate(qa.q, load_point(xyz, i));
+        out[3 * i] = o.x; out[3 * i + 1] = o.y; out[3 * i + 2] = o.z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a2 (+a4): one view, streaming.  24 B (f64) or 12 B (f32) in, 8 B uv + 1 B inside out per point.
+// The view record arrives in the kernarg segment -> SGPRs (wave-uniform).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool WRITE_UV, bool WRITE_INSIDE>
+__global__ __launch_bounds__(F3D_BLOCK) void k_project_view(const T* __restrict__ xyz, int64_t n, f3d_view vw,
+                                                             int32_t* __restrict__ uv, uint8_t* __restrict__ inside) {
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const f3d_p3 p = load_point(xyz, i);
+        if (WRITE_UV) {
+            const f3d_p3 h = f3d_project_h(vw.K, vw.qinv, vw.t, p);
+            uv[i] = f3d_floor_to_i32(h.x / h.z);                       // camera_utils.py:24-25
+            uv[n + i] = f3d_floor_to_i32(h.y / h.z);
+        }
+        if (WRITE_INSIDE) inside[i] = f3d_inside_view(vw, p) ? 1 : 0;
+    }
+}
+
+// a4 with an arbitrary plane list (<= F3D_PLANES_PER_LAUNCH per launch, chained with `accumulate`)
+template <typename T>
+__global__ __launch_bounds__(F3D_BLOCK) void k_inside_polyhedra(const T* __restrict__ xyz, int64_t n, f3d_plane_args pa,
+                                                                 uint8_t* __restrict__ inside) {
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const f3d_p3 p = load_point(xyz, i);
+        bool in = pa.accumulate ? (inside[i] != 0) : true;
+        for (int m = 0; m < pa.m; ++m) in = in & (f3d_plane_dp(pa.pt[m], pa.n[m], p) >= 0.0);
+        inside[i] = in ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused multi-view kernel: project -> sample -> vote -> segment.
+//
+// One thread owns one point for a tile of 256 points; it keeps xyz in registers and walks the V
+// views.  The view record (53 doubles) is read through scalar loads (wave-uniform address), so the
+// fp64 VALU instructions take it from SGPRs and no LDS/VGPR is spent on it.
+//
+// Per view: (1) conservative frustum pre-cull, 3 FMAs per plane against n.p - off with an error
+// margin: "surely outside" lanes skip the view, "surely inside" lanes skip the exact plane test,
+// only lanes within the margin of a plane evaluate the reference's exact arithmetic
+// (f3d_inside_view) -- so the result is always the exact test's.  (2) exact canonical projection,
+// IEEE divisions, floor.  (3) bounds test, 1-byte mask gather (L2 / Infinity-Cache resident
+// masks).  (4) vote.
+//
+// Votes.  MODE_HIST8/16: a per-thread histogram in LDS laid out [label/4 (or /2)][thread] so that a
+// wave's accesses fall on 64 different dwords of consecutive banks (conflict-free); the vote is
+// one returning ds_add on the packed dword, and the running argmax (count desc, label asc -- the
+// first-maximum rule of np.argmax) is updated from the returned count, so no final scan is
+// needed without a filter.  MODE_FILTER8: with <= 8 filter classes only their counters and the
+// total matter: 8 register counters, no LDS.
+// ------------------------------------------------------------------------------------------
+enum { MODE_HIST8 = 0, MODE_HIST16 = 1, MODE_FILTER8 = 2 };
+
+// k-th entry of filter_classes: short lists travel in the kernarg, long ones in device memory
+__device__ __forceinline__ int filter_at(const f3d_filter_args& flt, int k) {
+    return (flt.nfilter <= 8) ? flt.cls[k & 7] : flt.cls_dev[k];
+}
+
+template <int MODE>
+struct hist_traits;
+template <> struct hist_traits<MODE_HIST8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
+template <> struct hist_traits<MODE_HIST16> { static constexpr int per_word = 2, shift = 1, bits = 16; static constexpr uint32_t mask = 0xFFFFu; };
+template <> struct hist_traits<MODE_FILTER8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
+
+template <typename T, int MODE, bool WRITE_VOTES>
+__global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, int64_t n,
+                                                     const f3d_view* __restrict__ views, int nviews,
+                                                     const uint8_t* __restrict__ masks, int H, int W,
+                                                     int nclasses, f3d_filter_args flt, double threshold,
+                                                     int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
+                                                     int* __restrict__ err) {
+    using HT = hist_traits<MODE>;
+    extern __shared__ uint32_t hist[];                     // [words_per_thread][F3D_BLOCK]
+    const int tid = threadIdx.x;
+    const int ncols = nclasses + 1;
+    const int words = (ncols + HT::per_word - 1) >> HT::shift;
+    const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
+    const size_t plane = (size_t)H * (size_t)W;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * F3D_BLOCK + tid;
+        const bool live = i < n;
+        f3d_p3 p = {0.0, 0.0, 0.0};
+        if (live) p = load_point(xyz, i);
+        const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
+        const bool finite = pscale < 1.0e300;              // false for inf / NaN coordinates
+
+        if (MODE != MODE_FILTER8) {
+            for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;   // own column only: no barrier
+        }
+        int total = 0, best_c = 0, best_l = 0;
+        int fc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+        for (int v = 0; v < nviews; ++v) {
+            const f3d_view& vw = views[v];
+            // (1) conservative pre-cull
+            const double marg = __builtin_fma(vw.cull_rel, pscale, vw.cull_abs);
+            bool maybe = live, sure = finite;
+#pragma unroll
+            for (int m = 0; m < F3D_NPLANES; ++m) {
+                const double a = __builtin_fma(vw.plane_n[m][0], p.x,
+                                 __builtin_fma(vw.plane_n[m][1], p.y,
+                                 __builtin_fma(vw.plane_n[m][2], p.z, -vw.plane_off[m])));
+                maybe = maybe & (a > -marg);
+                sure = sure & (a > marg);
+            }
+            if (!maybe) continue;
+            if (!sure) {
+                if (!f3d_inside_view(vw, p)) continue;      // the reference's exact test decides
+            }
+            // (2) exact projection
+            const f3d_p3 h = f3d_project_h(vw.K, vw.qinv, vw.t, p);
+            const double fu = floor(h.x / h.z), fv = floor(h.y / h.z);
+            // (3) bounds + gather  (NaN compares false)
+            if (!(fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H)) continue;
+            const int label = masks[(size_t)v * plane + (size_t)(int)fv * (size_t)W + (size_t)(int)fu];
+            if (label > nclasses) { atomicOr(err, F3D_DEVERR_INDEX); continue; }   // IndexError in the reference
+            // (4) vote
+            ++total;
+            if (MODE == MODE_FILTER8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) fc[k] += (label == flt.cls[k]) ? 1 : 0;
+            } else {
+                const int sh = (label & (HT::per_word - 1)) * HT::bits;
+                const uint32_t old = atomicAdd(&hist[(label >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
+                const int c = (int)((old >> sh) & HT::mask) + 1;
+                if (c > best_c || (c == best_c && label < best_l)) { best_c = c; best_l = label; }
+            }
+        }
+
+        // ---- VotingSegmentation.segment (voting.py:120-135) for this point
+        int64_t cls;
+        int win_c, win_i;
+        if (MODE == MODE_FILTER8) {
+            win_c = fc[0]; win_i = 0;
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                if (k < flt.nfilter && fc[k] > win_c) { win_c = fc[k]; win_i = k; }     // first maximum wins
+        } else if (flt.nfilter > 0) {
+            win_c = -1; win_i = 0;
+            for (int k = 0; k < flt.nfilter; ++k) {
+                const int l = filter_at(flt, k);
+                int c = 0;
+                if (l >= 0 && l < ncols) c = (int)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
+                if (c > win_c) { win_c = c; win_i = k; }
+            }
+        } else {
+            win_c = best_c; win_i = best_l;
+        }
+        if (total == 0) cls = nclasses;                                            // :126
+        else {
+            cls = win_i;
+            if ((double)win_c / (double)total < threshold) cls = nclasses;         // :128-130
+            if (win_c == 0) cls = nclasses;                                        // :131
+        }
+        if (flt.nfilter > 0) {                                                     // sequential remap (Q3)
+            if (MODE == MODE_FILTER8) {
+                int64_t r = cls;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < flt.nfilter && r == k) r = flt.cls[k];
+                cls = r;
+            } else {
+                int64_t r = cls;
+                for (int k = 0; k < flt.nfilter; ++k) if (r == k) r = filter_at(flt, k);
+                cls = r;
+            }
+        }
+        if (live) classes[i] = cls;
+        if (WRITE_VOTES && live) {
+            for (int l = 0; l < ncols; ++l)
+                votes_out[(size_t)i * ncols + l] =
+                    (uint16_t)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a8: segment over a dense float64 votes matrix (HBM streaming: ncols*8 B in, 8 B out per point).
+// 16 lanes per row, 4 rows per wave; each lane streams 16-B (ncols even) or 8-B pieces of its row.
+// ------------------------------------------------------------------------------------------
+template <bool VEC2>
+__global__ __launch_bounds__(F3D_BLOCK) void k_segment_votes(const double* __restrict__ votes, int64_t npts, int ncols,
+                                                              int nclasses, double threshold, f3d_filter_args flt,
+                                                              int64_t* __restrict__ classes) {
+    const int lane16 = threadIdx.x & 15;
+    const int64_t group = ((int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x) >> 4;
+    const int64_t ngroups = ((int64_t)gridDim.x * F3D_BLOCK) >> 4;
+    for (int64_t row = group; row < npts; row += ngroups) {
+        const double* r = votes + (size_t)row * ncols;
+        double total = 0.0, best = -INFINITY;
+        int besti = 0x7fffffff;
+        if (VEC2) {
+            const double2* r2 = reinterpret_cast<const double2*>(r);
+            const int n2 = ncols >> 1;
+            for (int c = lane16; c < n2; c += 16) {
+                const double2 x = r2[c];
+                total += x.x; total += x.y;
+                if (x.x > best) { best = x.x; besti = 2 * c; }
+                if (x.y > best) { best = x.y; besti = 2 * c + 1; }
+            }
+        } else {
+            for (int c = lane16; c < ncols; c += 16) {
+                const double x = r[c];
+                total += x;
+                if (x > best) { best = x; besti = c; }
+            }
+        }
+        if (flt.nfilter > 0) {                       // votes[:, filter_classes]: position in the list is the index
+            best = -INFINITY; besti = 0x7fffffff;
+            for (int k = lane16; k < flt.nfilter; k += 16) {
+                const int l = filter_at(flt, k);
+                const double x = r[l];
+                if (x > best) { best = x; besti = k; }
+            }
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            total += __shfl_xor(total, off, 16);
+            const double ob = __shfl_xor(best, off, 16);
+            const int oi = __shfl_xor(besti, off, 16);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane16 == 0) {
+            int64_t cls = besti;
+            if (!(total > 0.0)) cls = nclasses;
+            else if (best / total < threshold) cls = nclasses;
+            if (best == 0.0) cls = nclasses;
+            if (flt.nfilter > 0) {
+                int64_t q = cls;
+                for (int k = 0; k < flt.nfilter; ++k) {
+                    if (q == k) q = filter_at(flt, k);
+                }
+                cls = q;
+            }
+            classes[row] = cls;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a7: one frame of the uv2pt scatter vote with quirk Q1 (each distinct (point,label) pair of a
+// frame adds exactly 1).  Pass 1 validates every index (NumPy raises IndexError before writing
+// anything); pass 2 inserts the 64-bit key point*ncols+label into an open-addressing set with
+// atomicCAS -- the lane whose insert creates the key performs the single, race-free increment.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(F3D_BLOCK) void k_vote_validate(const int32_t* __restrict__ uv2pt, const uint8_t* __restrict__ mask,
+                                                              int64_t hw, int64_t npts, int ncols, int* __restrict__ err) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < hw; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t p = uv2pt[i];
+        if (p == -1) continue;
+        if (p >= npts || p < -npts || (int)mask[i] >= ncols) bad = true;
+    }
+    if (bad) atomicOr(err, F3D_DEVERR_INDEX);
+}
+
+__global__ __launch_bounds__(F3D_BLOCK) void k_vote_uv2pt(const int32_t* __restrict__ uv2pt, const uint8_t* __restrict__ mask,
+                                                           int64_t hw, double* __restrict__ votes, int64_t npts, int ncols,
+                                                           unsigned long long* __restrict__ table, uint64_t table_mask,
+                                                           const int* __restrict__ err) {
+    if (*err & F3D_DEVERR_INDEX) return;
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < hw; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        int64_t p = uv2pt[i];
+        if (p == -1) continue;
+        if (p < 0) p += npts;                                         // NumPy negative-index wrap
+        const unsigned long long key = (unsigned long long)p * (unsigned long long)ncols + mask[i];
+        uint64_t slot = (key * 0x9E3779B97F4A7C15ull) >> 20;
+        for (;;) {
+            slot &= table_mask;
+            const unsigned long long prev = atomicCAS(&table[slot], ~0ull, key);
+            if (prev == ~0ull) { votes[key] += 1.0; break; }          // first of its pair in this frame
+            if (prev == key) break;                                   // duplicate pair: adds nothing (Q1)
+            ++slot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a9: [C, HW] float32 logits -> uint8 mask.  A block stages 64 pixels x C classes in LDS (read
+// from HBM once, 256-B coalesced rows), 4 threads per pixel: argmax (first maximum), then
+// exp(x - max) summed in class order per thread slice and combined; max softmax = 1 / sum.
+// ------------------------------------------------------------------------------------------
+#define F3D_SEM_PIX 64
+__global__ __launch_bounds__(F3D_BLOCK) void k_sem_to_mask(const float* __restrict__ sem, int C, int64_t hw, float conf,
+                                                            int low_label, uint8_t* __restrict__ mask) {
+    extern __shared__ float tile[];                                   // [C][F3D_SEM_PIX]
+    const int tid = threadIdx.x;
+    const int64_t ntiles = (hw + F3D_SEM_PIX - 1) / F3D_SEM_PIX;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t base = t * F3D_SEM_PIX;
+        const int px = tid & (F3D_SEM_PIX - 1);
+        for (int c = tid >> 6; c < C; c += F3D_BLOCK / F3D_SEM_PIX) {
+            const int64_t g = base + px;
+            tile[c * F3D_SEM_PIX + px] = (g < hw) ? sem[(size_t)c * hw + g] : 0.0f;
+        }
+        __syncthreads();
+        // 4 threads per pixel: thread (px, part) scans classes part, part+4, ...
+        const int part = tid >> 6;
+        float best = -INFINITY; int besti = 0x7fffffff;
+        for (int c = part; c < C; c += 4) {
+            const float x = tile[c * F3D_SEM_PIX + px];
+            if (x > best) { best = x; besti = c; }
+        }
+        __shared__ float sbest[F3D_BLOCK]; __shared__ int sidx[F3D_BLOCK]; __shared__ float ssum[F3D_BLOCK];
+        sbest[tid] = best; sidx[tid] = besti;
+        __syncthreads();
+        float m = sbest[px]; int mi = sidx[px];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float ob = sbest[q * F3D_SEM_PIX + px]; const int oi = sidx[q * F3D_SEM_PIX + px];
+            if (ob > m || (ob == m && oi < mi)) { m = ob; mi = oi; }
+        }
+        float s = 0.0f;
+        for (int c = part; c < C; c += 4) s += expf(tile[c * F3D_SEM_PIX + px] - m);
+        ssum[tid] = s;
+        __syncthreads();
+        if (part == 0 && base + px < hw) {
+            const float tot = ((ssum[px] + ssum[F3D_SEM_PIX + px]) + ssum[2 * F3D_SEM_PIX + px]) + ssum[3 * F3D_SEM_PIX + px];
+            int lab = mi;
+            if (conf != 0.0f && 1.0f / tot < conf) lab = low_label;
+            mask[base + px] = (uint8_t)lab;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a10/a11: oriented-box membership.  Thread per point; boxes (c, R, e) staged through LDS in
+// chunks of 64; the point's membership bitset lives in LDS as [word][thread] (conflict-free), is
+// optionally streamed out (uint32 [n, ceil(B/32)]) and feeds the B x B co-occurrence matrix
+// ("the two index lists share a point", merge_intersecting_bb.py:64-66,88-90): only points that
+// lie in at least one box do any pair work, and cooc bytes are written once (benign same-value race).
+// ------------------------------------------------------------------------------------------
+#define F3D_OBB_CHUNK 64
+template <typename T>
+__global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb(const T* __restrict__ xyz, int64_t n,
+                                                              const f3d_obb* __restrict__ boxes, int B,
+                                                              uint32_t* __restrict__ bits, uint8_t* __restrict__ cooc) {
+    extern __shared__ uint32_t obb_lds[];                   // [words][F3D_BLOCK] bitset, then the box chunk
+    const int words = (B + 31) >> 5;
+    uint32_t* myb = obb_lds;
+    f3d_obb* sb = reinterpret_cast<f3d_obb*>(obb_lds + (size_t)words * F3D_BLOCK);
+    const int tid = threadIdx.x;
+    const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * F3D_BLOCK + tid;
+        const bool live = i < n;
+        f3d_p3 p = {0, 0, 0};
+        if (live) p = load_point(xyz, i);
+        uint32_t any = 0;
+        for (int b0 = 0; b0 < B; b0 += F3D_OBB_CHUNK) {
+            const int nb = min(F3D_OBB_CHUNK, B - b0);
+            __syncthreads();
+            {
+                const double* src = reinterpret_cast<const double*>(boxes + b0);
+                double* dst = reinterpret_cast<double*>(sb);
+                for (int k = tid; k < nb * (int)(sizeof(f3d_obb) / 8); k += F3D_BLOCK) dst[k] = src[k];
+            }
+            __syncthreads();
+            for (int w0 = 0; w0 < nb; w0 += 32) {
+                uint32_t word = 0;
+                const int lim = min(32, nb - w0);
+                for (int k = 0; k < lim; ++k) {
+                    const f3d_obb& bx = sb[w0 + k];
+                    const double d0 = p.x - bx.center[0], d1 = p.y - bx.center[1], d2 = p.z - bx.center[2];
+                    bool in = live;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const double pr = (d0 * bx.R[a] + d1 * bx.R[3 + a]) + d2 * bx.R[6 + a];
+                        in = in & (fabs(pr) <= bx.extent[a] / 2);
+                    }
+                    word |= in ? (1u << k) : 0u;
+                }
+                myb[((b0 + w0) >> 5) * F3D_BLOCK + tid] = word;
+                any |= word;
+                if (live && bits) bits[(size_t)i * words + ((b0 + w0) >> 5)] = word;
+            }
+        }
+        if (cooc && any) {
+            for (int wa = 0; wa < words; ++wa) {
+                const uint32_t A = myb[wa * F3D_BLOCK + tid];
+                if (!A) continue;
+                for (int wc = 0; wc < words; ++wc) {
+                    const uint32_t Cw = myb[wc * F3D_BLOCK + tid];
+                    if (!Cw) continue;
+                    for (uint32_t a = A; a; a &= a - 1) {
+                        const size_t ia = (size_t)(wa * 32 + __builtin_ctz(a));
+                        for (uint32_t c = Cw; c; c &= c - 1) {
+                            const size_t ic = (size_t)(wc * 32 + __builtin_ctz(c));
+                            if (!cooc[ia * B + ic]) cooc[ia * B + ic] = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(F3D_BLOCK) void k_relabel(int64_t* __restrict__ ids, int64_t n, int64_t from, int64_t to,
+                                                        unsigned long long* __restrict__ count) {
+    unsigned long long local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        if (ids[i] == from) { ids[i] = to; ++local; }
+    }
+    if (count) {
+        for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off, 64);
+        if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+    }
+}
+
+inline int grid_for(int64_t n, int per_block, int cap) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+// =============================================================================================
+// launchers (called from f3d_capi.cpp)
+// =============================================================================================
+#define F3D_GRID_CAP (256 * 8 * 4)      // 256 CUs x 8 blocks, x4 so that tails stay short
+
+hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], double* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    quat_arg qa; for (int k = 0; k < 4; ++k) qa.q[k] = q[k];
+    hipLaunchKernelGGL(k_rotate, dim3(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), dim3(F3D_BLOCK), 0, s, xyz, n, qa, out);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_project_view(const void* xyz, int dtype, int64_t n, const f3d_view& vw, int32_t* uv, uint8_t* inside,
+                                   hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+#define F3D_PV(T, U, I) hipLaunchKernelGGL((k_project_view<T, U, I>), g, b, 0, s, (const T*)xyz, n, vw, uv, inside)
+    if (dtype == F3D_F64) {
+        if (uv && inside) F3D_PV(double, true, true); else if (uv) F3D_PV(double, true, false); else F3D_PV(double, false, true);
+    } else {
+        if (uv && inside) F3D_PV(float, true, true); else if (uv) F3D_PV(float, true, false); else F3D_PV(float, false, true);
+    }
+#undef F3D_PV
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, const f3d_plane_args& pa, uint8_t* inside,
+                                       hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+    if (dtype == F3D_F64) hipLaunchKernelGGL(k_inside_polyhedra<double>, g, b, 0, s, (const double*)xyz, n, pa, inside);
+    else hipLaunchKernelGGL(k_inside_polyhedra<float>, g, b, 0, s, (const float*)xyz, n, pa, inside);
+    return hipGetLastError();
+}
+
+size_t f3d_fuse_lds_bytes(int mode, int nclasses) {
+    const int ncols = nclasses + 1;
+    if (mode == MODE_FILTER8) return 0;
+    const int per_word = (mode == MODE_HIST8) ? 4 : 2;
+    return (size_t)((ncols + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);
+}
+
+int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
+    if (nfilter > 0 && nfilter <= 8 && !want_votes) return MODE_FILTER8;
+    return nviews <= 255 ? MODE_HIST8 : MODE_HIST16;
+}
+
+hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                           const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
+                           int64_t* classes, uint16_t* votes, int* err, int grid_blocks, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);
+    const size_t lds = f3d_fuse_lds_bytes(mode, nclasses);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
+    int grid = grid_blocks > 0 ? grid_blocks : (int)(ntiles < F3D_GRID_CAP ? ntiles : F3D_GRID_CAP);
+    if (grid > ntiles) grid = (int)ntiles;
+    const dim3 g(grid), b(F3D_BLOCK);
+#define F3D_FUSE(T, M, V)                                                                                      \
+    do {                                                                                                       \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_fuse<T, M, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, masks, h, w,  \
+                           nclasses, flt, threshold, classes, votes, err);                                     \
+    } while (0)
+#define F3D_FUSE_T(T)                                                                                          \
+    do {                                                                                                       \
+        if (mode == MODE_FILTER8) F3D_FUSE(T, MODE_FILTER8, false);                                            \
+        else if (mode == MODE_HIST8) { if (votes) F3D_FUSE(T, MODE_HIST8, true); else F3D_FUSE(T, MODE_HIST8, false); } \
+        else { if (votes) F3D_FUSE(T, MODE_HIST16, true); else F3D_FUSE(T, MODE_HIST16, false); }              \
+    } while (0)
+    if (dtype == F3D_F64) F3D_FUSE_T(double); else F3D_FUSE_T(float);
+#undef F3D_FUSE_T
+#undef F3D_FUSE
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_segment_votes(const double* votes, int64_t npts, int ncols, int nclasses, double threshold,
+                                    const f3d_filter_args& flt, int64_t* classes, hipStream_t s) {
+    if (npts <= 0) return hipSuccess;
+    const dim3 g(grid_for(npts, F3D_BLOCK / 16, F3D_GRID_CAP)), b(F3D_BLOCK);
+    const bool vec2 = (ncols % 2 == 0) && ((reinterpret_cast<uintptr_t>(votes) & 15) == 0);
+    if (vec2) hipLaunchKernelGGL(k_segment_votes<true>, g, b, 0, s, votes, npts, ncols, nclasses, threshold, flt, classes);
+    else hipLaunchKernelGGL(k_segment_votes<false>, g, b, 0, s, votes, npts, ncols, nclasses, threshold, flt, classes);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols,
+                                 unsigned long long* table, uint64_t table_slots, int* err, hipStream_t s) {
+    if (hw <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(table, 0xFF, table_slots * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const dim3 g(grid_for(hw, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+    hipLaunchKernelGGL(k_vote_validate, g, b, 0, s, uv2pt, mask, hw, npts, ncols, err);
+    hipLaunchKernelGGL(k_vote_uv2pt, g, b, 0, s, uv2pt, mask, hw, votes, npts, ncols, table, (uint64_t)(table_slots - 1), err);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_sem_to_mask(const float* sem, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s) {
+    if (hw <= 0) return hipSuccess;
+    const size_t lds = (size_t)c * F3D_SEM_PIX * sizeof(float);
+    if (lds > 150 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_sem_to_mask, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const dim3 g(grid_for(hw, F3D_SEM_PIX, F3D_GRID_CAP)), b(F3D_BLOCK);
+    hipLaunchKernelGGL(k_sem_to_mask, g, b, lds, s, sem, c, hw, conf, low_label, mask);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, uint32_t* bits,
+                                    uint8_t* cooc, hipStream_t s) {
+    if (n <= 0 || b <= 0) return hipSuccess;
+    if (b > F3D_OBB_MAX_BOXES) return hipErrorInvalidValue;
+    if (cooc) {
+        hipError_t e = hipMemsetAsync(cooc, 0, (size_t)b * b, s);
+        if (e != hipSuccess) return e;
+    }
+    const size_t lds = (size_t)((b + 31) / 32) * F3D_BLOCK * sizeof(uint32_t) + F3D_OBB_CHUNK * sizeof(f3d_obb);
+    const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), blk(F3D_BLOCK);
+    if (dtype == F3D_F64) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_in_obb<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_points_in_obb<double>, g, blk, lds, s, (const double*)xyz, n, boxes_dev, b, bits, cooc);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_in_obb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_points_in_obb<float>, g, blk, lds, s, (const float*)xyz, n, boxes_dev, b, bits, cooc);
+    }
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_relabel(int64_t* ids, int64_t n, int64_t from, int64_t to, unsigned long long* count, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_relabel, dim3(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), dim3(F3D_BLOCK), 0, s, ids, n, from, to, count);
+    return hipGetLastError();
+}

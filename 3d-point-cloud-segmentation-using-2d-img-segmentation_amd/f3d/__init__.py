@@ -1,0 +1,375 @@
+"""ctypes binding of libf3d_hip.so (include/f3d.h) -- the only way Python reaches the kernels.
+
+There is deliberately no CPU fallback here: if the library is missing or no HIP
+device is usable, every compute call raises ``F3DUnavailable``.
+
+Two call styles, mirroring the C-ABI:
+* NumPy in / NumPy out (host-pointer entry points) -- what the drop-in modules
+  ``Fusion3DSeg.*`` use;
+* ``*_dev`` methods taking raw device pointers (``tensor.data_ptr()``) and a
+  stream handle -- what ``bench.py`` and device-resident pipelines use.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+__all__ = ['F3DError', 'F3DUnavailable', 'Context', 'default_context', 'library', 'library_path',
+           'views_build', 'frustum_data', 'quat_inverse', 'VIEW_DOUBLES', 'F64', 'F32']
+
+F64, F32 = 0, 1
+OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_ZERO_QUAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5
+VIEW_DOUBLES = 53            # sizeof(f3d_view) / 8
+OBB_DOUBLES = 15             # sizeof(f3d_obb) / 8
+MAX_OBB = 4096
+
+
+class F3DError(RuntimeError):
+    pass
+
+
+class F3DUnavailable(F3DError):
+    """libf3d_hip.so is not built/loadable or there is no HIP device."""
+
+
+_lib = None
+
+
+def library_path():
+    return Path(__file__).resolve().parent / 'libf3d_hip.so'
+
+
+def library():
+    """Load libf3d_hip.so once and declare every prototype of include/f3d.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.is_file():
+        raise F3DUnavailable(f'{path} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                             f'(or `make -C {path.parent.parent / "csrc"}`); there is no CPU fallback')
+    try:                         # share torch's HIP runtime when torch is in the process (same SONAME)
+        import torch  # noqa: F401
+    except Exception:            # torch is plumbing, not a requirement of the binding
+        pass
+    try:
+        lib = C.CDLL(str(path), mode=getattr(os, 'RTLD_NOW', 2))
+    except OSError as exc:
+        raise F3DUnavailable(f'cannot load {path}: {exc}') from exc
+
+    vp, i32, i64, dbl, flt = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_float
+    protos = {
+        'f3d_version': (i32, []),
+        'f3d_ctx_create': (vp, [i32]),
+        'f3d_ctx_destroy': (None, [vp]),
+        'f3d_last_error': (C.c_char_p, [vp]),
+        'f3d_ctx_synchronize': (i32, [vp]),
+        'f3d_ctx_stream': (vp, [vp]),
+        'f3d_quat_inverse': (i32, [vp, vp]),
+        'f3d_frustum_data': (i32, [vp, dbl, dbl, vp, vp, i32, vp, vp, vp]),
+        'f3d_views_build': (i32, [vp, dbl, dbl, vp, vp, i32, dbl, vp]),
+        'f3d_rotate_f64': (i32, [vp, vp, i64, vp, vp]),
+        'f3d_points2pixel_f64': (i32, [vp, vp, i64, vp, vp, vp, vp]),
+        'f3d_points2pixel_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, vp, vp]),
+        'f3d_inside_polyhedra_f64': (i32, [vp, vp, i64, vp, vp, i32, vp]),
+        'f3d_inside_polyhedra_dev': (i32, [vp, vp, i32, i64, vp, vp, i32, vp, vp]),
+        'f3d_project_view_f64': (i32, [vp, vp, i64, vp, vp, vp]),
+        'f3d_project_view_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),
+        'f3d_project_vote_argmax': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp]),
+        'f3d_project_vote_argmax_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp, vp]),
+        'f3d_take_device_error': (i32, [vp, vp]),
+        'f3d_vote_uv2pt': (i32, [vp, vp, vp, i64, vp, i64, i32]),
+        'f3d_vote_uv2pt_dev': (i32, [vp, vp, vp, i64, vp, i64, i32, vp]),
+        'f3d_segment_votes': (i32, [vp, vp, i64, i32, i32, dbl, vp, i32, vp]),
+        'f3d_segment_votes_dev': (i32, [vp, vp, i64, i32, i32, dbl, vp, i32, vp, vp]),
+        'f3d_sem_logits_to_mask': (i32, [vp, vp, i32, i64, flt, i32, vp]),
+        'f3d_sem_logits_to_mask_dev': (i32, [vp, vp, i32, i64, flt, i32, vp, vp]),
+        'f3d_points_in_obb': (i32, [vp, vp, i32, i64, vp, i32, vp, vp]),
+        'f3d_points_in_obb_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, vp, vp]),
+        'f3d_relabel': (i32, [vp, vp, i64, i64, i64, vp]),
+        'f3d_relabel_dev': (i32, [vp, vp, i64, i64, i64, vp, vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    lib._f3d_symbols = tuple(protos)
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f'expected shape {tuple(shape)}, got {a.shape}')
+    return a
+
+
+def _raise(code, msg):
+    if code == ERR_INDEX:
+        raise IndexError(msg)
+    if code == ERR_ZERO_QUAT:
+        raise ZeroDivisionError(msg)
+    if code == ERR_INVALID:
+        raise ValueError(msg)
+    if code == ERR_NOMEM:
+        raise MemoryError(msg)
+    if code == ERR_HIP:
+        raise F3DUnavailable(msg)
+    raise F3DError(f'f3d error {code}: {msg}')
+
+
+# ------------------------------------------------------------------ host geometry (no device)
+def quat_inverse(q_wxyz):
+    q = _f64(q_wxyz, (4,))
+    out = np.empty(4)
+    rc = library().f3d_quat_inverse(_ptr(q), _ptr(out))
+    if rc:
+        _raise(rc, 'a zero quaternion cannot be inverted')
+    return out
+
+
+def frustum_data(K, w, h, wxyzs, translations):
+    """eyes [V,3], lookats [V,3], face_normals [V,4,3] of Fusion._get_frustum_data (fusion.py:119-132)."""
+    K = _f64(K, (3, 3))
+    q = _f64(np.atleast_2d(wxyzs))
+    t = _f64(np.atleast_2d(translations))
+    V = len(t)
+    if q.shape != (V, 4) or t.shape != (V, 3):
+        raise ValueError('wxyzs must be [V,4] and translations [V,3]')
+    eyes, look, nrm = np.empty((V, 3)), np.empty((V, 3)), np.empty((V, 4, 3))
+    rc = library().f3d_frustum_data(_ptr(K), float(w), float(h), _ptr(q), _ptr(t), V, _ptr(eyes), _ptr(look), _ptr(nrm))
+    if rc:
+        _raise(rc, 'f3d_frustum_data failed')
+    return eyes, look, nrm
+
+
+def views_build(K, w, h, wxyzs, translations, max_depth):
+    """Packed per-view records (float64 [V, 53]) consumed by the fused kernels."""
+    K = _f64(K, (3, 3))
+    q = _f64(np.atleast_2d(wxyzs))
+    t = _f64(np.atleast_2d(translations))
+    V = len(t)
+    if q.shape != (V, 4) or t.shape != (V, 3):
+        raise ValueError('wxyzs must be [V,4] and translations [V,3]')
+    out = np.zeros((V, VIEW_DOUBLES))
+    rc = library().f3d_views_build(_ptr(K), float(w), float(h), _ptr(q), _ptr(t), V, float(max_depth), _ptr(out))
+    if rc:
+        _raise(rc, 'a zero quaternion cannot be inverted' if rc == ERR_ZERO_QUAT else 'f3d_views_build failed')
+    return out
+
+
+def view_fields(views):
+    """Named sub-arrays of a [V,53] view table (for tests and debugging)."""
+    v = np.asarray(views)
+    return {'K': v[:, 0:9].reshape(-1, 3, 3), 'qinv': v[:, 9:13], 't': v[:, 13:16],
+            'plane_pt': v[:, 16:31].reshape(-1, 5, 3), 'plane_n': v[:, 31:46].reshape(-1, 5, 3),
+            'plane_off': v[:, 46:51], 'cull_rel': v[:, 51], 'cull_abs': v[:, 52]}
+
+
+def _xyz(points):
+    p = np.asarray(points)
+    if p.ndim != 2 or p.shape[1] != 3:
+        raise ValueError(f'points must be [N,3], got {p.shape}')
+    if p.dtype == np.float32:
+        return np.ascontiguousarray(p), F32
+    return np.ascontiguousarray(p, dtype=np.float64), F64
+
+
+def _filter(filter_classes):
+    if filter_classes is None:
+        return None, 0
+    f = np.ascontiguousarray(np.asarray(list(filter_classes)), dtype=np.int32)
+    return f, len(f)
+
+
+class Context:
+    """One f3d_ctx (device ordinal, stream, scratch arena).  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self._lib = library()
+        self._h = self._lib.f3d_ctx_create(int(device))
+        if not self._h:
+            raise F3DUnavailable(self._lib.f3d_last_error(None).decode() or 'f3d_ctx_create failed')
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.f3d_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            _raise(rc, self._lib.f3d_last_error(self._h).decode())
+
+    @property
+    def stream(self):
+        return self._lib.f3d_ctx_stream(self._h)
+
+    def synchronize(self):
+        self._check(self._lib.f3d_ctx_synchronize(self._h))
+
+    # ---------------------------------------------------------------- NumPy (host pointer) calls
+    def rotate(self, points, q_wxyz):
+        p = _f64(points)
+        if p.ndim != 2 or p.shape[1] != 3:
+            raise ValueError('points must be [N,3]')
+        q = _f64(q_wxyz, (4,))
+        out = np.empty_like(p)
+        self._check(self._lib.f3d_rotate_f64(self._h, _ptr(p), len(p), _ptr(q), _ptr(out)))
+        return out
+
+    def points2pixel(self, points, intrinsic, quat, translation):
+        p = _f64(points)
+        if p.ndim != 2 or p.shape[1] != 3:
+            raise ValueError('points must be [N,3]')
+        K, q, t = _f64(intrinsic, (3, 3)), _f64(quat, (4,)), _f64(translation, (3,))
+        uv = np.empty((2, len(p)), np.int32)
+        self._check(self._lib.f3d_points2pixel_f64(self._h, _ptr(p), len(p), _ptr(K), _ptr(q), _ptr(t), _ptr(uv)))
+        return uv
+
+    def inside_polyhedra(self, points, plane_points, normals):
+        p = _f64(points)
+        if p.ndim != 2 or p.shape[1] != 3:
+            raise ValueError('points must be [N,3]')
+        pp, nr = _f64(plane_points), _f64(normals)
+        if pp.shape != nr.shape or pp.ndim != 2 or pp.shape[1] != 3:
+            raise ValueError('plane_points and normals must both be [M,3]')
+        out = np.empty(len(p), np.uint8)
+        self._check(self._lib.f3d_inside_polyhedra_f64(self._h, _ptr(p), len(p), _ptr(pp), _ptr(nr), len(pp), _ptr(out)))
+        return out.view(np.bool_)
+
+    def project_view(self, points, view, want_uv=True, want_inside=True):
+        p = _f64(points)
+        v = _f64(view, (VIEW_DOUBLES,))
+        uv = np.empty((2, len(p)), np.int32) if want_uv else None
+        ins = np.empty(len(p), np.uint8) if want_inside else None
+        self._check(self._lib.f3d_project_view_f64(self._h, _ptr(p), len(p), _ptr(v), _ptr(uv), _ptr(ins)))
+        return uv, (None if ins is None else ins.view(np.bool_))
+
+    def project_vote_argmax(self, points, views, masks, nclasses=133, threshold=0.5, filter_classes=None,
+                            return_votes=False):
+        p, dt = _xyz(points)
+        views = _f64(views)
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        if masks.ndim != 3 or views.ndim != 2 or views.shape[1] != VIEW_DOUBLES or len(views) != len(masks):
+            raise ValueError('views must be [V,53] and masks uint8 [V,H,W]')
+        V, H, W = masks.shape
+        f, nf = _filter(filter_classes)
+        cls = np.empty(len(p), np.int64)
+        votes = np.empty((len(p), nclasses + 1), np.uint16) if return_votes else None
+        self._check(self._lib.f3d_project_vote_argmax(self._h, _ptr(p), dt, len(p), _ptr(views), V, _ptr(masks), H, W,
+                                                      int(nclasses), _ptr(f), nf, float(threshold), _ptr(cls), _ptr(votes)))
+        return (cls, votes) if return_votes else cls
+
+    def vote_uv2pt(self, votes, uv2pt, mask_flat):
+        """In-place on `votes` (float64 [npts, ncols], C-contiguous), like voting.py:98."""
+        if votes.dtype != np.float64 or not votes.flags.c_contiguous or votes.ndim != 2:
+            raise ValueError('votes must be a C-contiguous float64 [npts, ncols] array')
+        lut = np.ascontiguousarray(uv2pt, dtype=np.int32).reshape(-1)
+        m = np.ascontiguousarray(mask_flat, dtype=np.uint8).reshape(-1)
+        if len(lut) != len(m):
+            raise IndexError(f'shape mismatch: uv2pt has {len(lut)} entries, mask {len(m)}')
+        self._check(self._lib.f3d_vote_uv2pt(self._h, _ptr(lut), _ptr(m), len(lut), _ptr(votes), votes.shape[0], votes.shape[1]))
+        return votes
+
+    def segment_votes(self, votes, nclasses, threshold=0.5, filter_classes=None):
+        v = _f64(votes)
+        if v.ndim != 2:
+            raise ValueError('votes must be [npts, ncols]')
+        f, nf = _filter(filter_classes)
+        cls = np.empty(len(v), np.int64)
+        if v.shape[1] == 0:
+            raise ValueError('attempt to get argmax of an empty sequence')
+        self._check(self._lib.f3d_segment_votes(self._h, _ptr(v), v.shape[0], v.shape[1], int(nclasses), float(threshold),
+                                                _ptr(f), nf, _ptr(cls)))
+        return cls
+
+    def sem_logits_to_mask(self, sem, conf_threshold=0.017, low_label=133):
+        s = np.ascontiguousarray(sem, dtype=np.float32)
+        if s.ndim != 3:
+            raise ValueError('sem must be [C,H,W]')
+        c, h, w = s.shape
+        out = np.empty((h, w), np.uint8)
+        self._check(self._lib.f3d_sem_logits_to_mask(self._h, _ptr(s), c, h * w, float(conf_threshold or 0.0), int(low_label), _ptr(out)))
+        return out
+
+    def points_in_obb(self, points, boxes, want_bits=True, want_cooc=True):
+        """boxes: float64 [B,15] = center(3), R row-major(9), extent(3).  Returns (inside bool [N,B] or None, cooc bool [B,B] or None)."""
+        p, dt = _xyz(points)
+        b = _f64(boxes)
+        if b.ndim != 2 or b.shape[1] != OBB_DOUBLES:
+            raise ValueError('boxes must be [B,15]')
+        B = len(b)
+        words = (B + 31) // 32
+        bits = np.zeros((len(p), words), np.uint32) if want_bits else None
+        cooc = np.zeros((B, B), np.uint8) if want_cooc else None
+        if B:
+            self._check(self._lib.f3d_points_in_obb(self._h, _ptr(p), dt, len(p), _ptr(b), B, _ptr(bits), _ptr(cooc)))
+        inside = None
+        if want_bits:
+            inside = np.unpackbits(bits.view(np.uint8), axis=1, bitorder='little')[:, :B].astype(bool)
+        return inside, (None if cooc is None else cooc.astype(bool))
+
+    def relabel(self, ids, from_id, to_id):
+        if ids.dtype != np.int64 or not ids.flags.c_contiguous:
+            raise ValueError('ids must be a C-contiguous int64 array')
+        cnt = np.zeros(1, np.int64)
+        self._check(self._lib.f3d_relabel(self._h, _ptr(ids), ids.size, int(from_id), int(to_id), _ptr(cnt)))
+        return int(cnt[0])
+
+    # ---------------------------------------------------------------- device-pointer calls
+    def project_vote_argmax_dev(self, xyz_ptr, dtype, n, views_ptr, nviews, masks_ptr, h, w, nclasses, threshold,
+                                filter_classes, classes_ptr, votes_ptr=None, stream=None):
+        f, nf = _filter(filter_classes)
+        self._check(self._lib.f3d_project_vote_argmax_dev(self._h, xyz_ptr, dtype, n, views_ptr, nviews, masks_ptr, h, w,
+                                                          int(nclasses), _ptr(f), nf, float(threshold), classes_ptr,
+                                                          votes_ptr, stream))
+
+    def take_device_error(self, stream=None):
+        self._check(self._lib.f3d_take_device_error(self._h, stream))
+
+    def project_view_dev(self, xyz_ptr, dtype, n, view, uv_ptr, inside_ptr, stream=None):
+        v = _f64(view, (VIEW_DOUBLES,))
+        self._check(self._lib.f3d_project_view_dev(self._h, xyz_ptr, dtype, n, _ptr(v), uv_ptr, inside_ptr, stream))
+
+    def segment_votes_dev(self, votes_ptr, npts, ncols, nclasses, threshold, filter_classes, classes_ptr, stream=None):
+        f, nf = _filter(filter_classes)
+        self._check(self._lib.f3d_segment_votes_dev(self._h, votes_ptr, npts, ncols, int(nclasses), float(threshold),
+                                                    _ptr(f), nf, classes_ptr, stream))
+
+    def vote_uv2pt_dev(self, uv2pt_ptr, mask_ptr, hw, votes_ptr, npts, ncols, stream=None):
+        self._check(self._lib.f3d_vote_uv2pt_dev(self._h, uv2pt_ptr, mask_ptr, hw, votes_ptr, npts, ncols, stream))
+
+    def sem_logits_to_mask_dev(self, sem_ptr, c, hw, conf, low_label, mask_ptr, stream=None):
+        self._check(self._lib.f3d_sem_logits_to_mask_dev(self._h, sem_ptr, c, hw, float(conf or 0.0), int(low_label), mask_ptr, stream))
+
+    def points_in_obb_dev(self, xyz_ptr, dtype, n, boxes, bits_ptr, cooc_ptr, stream=None):
+        b = _f64(boxes)
+        self._check(self._lib.f3d_points_in_obb_dev(self._h, xyz_ptr, dtype, n, _ptr(b), len(b), bits_ptr, cooc_ptr, stream))
+
+    def relabel_dev(self, ids_ptr, n, from_id, to_id, count_ptr=None, stream=None):
+        self._check(self._lib.f3d_relabel_dev(self._h, ids_ptr, n, int(from_id), int(to_id), count_ptr, stream))
+
+
+_default = {}
+
+
+def default_context(device=None):
+    """Process-wide context per device (LOCAL_RANK selects the device under torchrun)."""
+    if device is None:
+        device = int(os.environ.get('F3D_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    ctx = _default.get(device)
+    if ctx is None:
+        ctx = _default[device] = Context(device)
+    return ctx

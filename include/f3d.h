@@ -1,0 +1,188 @@
+/*
+ * f3d.h -- C-ABI of libf3d_hip.so: the MI355X (gfx950) implementation of the Fusion3DSeg hot
+ * path (per-point pinhole projection + frustum visibility, multi-view mask sampling and label
+ * voting/argmax, oriented-box membership/merge support).
+ *
+ * The reference is pure Python/NumPy and has no FFI; the boundary is its Python call surface
+ * (SURVEY.md 8(b)).  Each entry point below names the reference function (file:line, relative
+ * to the reference repository) whose arithmetic it replaces; INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add at each call site.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy types.
+ *   - every function returns F3D_OK (0) or a negative f3d_status; the text of the last error
+ *     of a context is available from f3d_last_error().
+ *   - functions without a "_dev" suffix take HOST pointers: inputs are copied to the device
+ *     through the context's scratch arena, the kernels run on the context's stream, outputs are
+ *     copied back, and the call returns after the stream has drained (NumPy drop-in).
+ *   - "_dev" functions take DEVICE pointers and a hipStream_t (as void*; NULL = the context's
+ *     own stream).  They only enqueue work: no allocation, no synchronisation (hipGraph-safe).
+ *   - the caller owns every buffer; the library keeps no caller pointer after a call returns
+ *     (host variants) / after the enqueued work has completed (_dev variants).
+ *   - a context is not thread-safe; use one per thread.  There is no global state.
+ *   - quaternions are (w, x, y, z) float64 and are NOT assumed to be normalised (quirk Q4).
+ *   - the library has no CPU fallback: without a HIP device every compute entry point fails
+ *     with F3D_ERR_HIP.
+ */
+#ifndef F3D_H
+#define F3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F3D_VERSION 100           /* 0.1.0 */
+#define F3D_MAX_FILTER 512        /* longest filter_classes list accepted */
+#define F3D_NPLANES 5             /* 4 frustum side planes + far plane (fusion.py:254-258) */
+
+typedef enum f3d_status {
+    F3D_OK = 0,
+    F3D_ERR_INVALID = -1,         /* bad argument (NULL, negative size, unsupported combination)  */
+    F3D_ERR_HIP = -2,             /* HIP runtime error / no device / extension not usable         */
+    F3D_ERR_INDEX = -3,           /* reference raises IndexError (voting.py:98): label or point id
+                                     out of range                                                 */
+    F3D_ERR_ZERO_QUAT = -4,       /* reference raises ZeroDivisionError (pyquaternion inverse)    */
+    F3D_ERR_NOMEM = -5
+} f3d_status;
+
+typedef enum f3d_dtype {
+    F3D_F64 = 0,                  /* xyz stored as float64 [N,3] row-major (the reference layout) */
+    F3D_F32 = 1                   /* xyz stored as float32 [N,3]; widened to f64 in registers     */
+} f3d_dtype;
+
+/* One camera view, in the form the kernels consume (all float64, 8-byte aligned, 53 doubles).
+ * Built on the host by f3d_views_build(); the fused kernel reads it through scalar loads /
+ * stages it in LDS. */
+typedef struct f3d_view {
+    double K[9];                  /* intrinsics, row-major (camera_utils.py:23)                   */
+    double qinv[4];               /* conj(q)/|q|^2 (w,x,y,z)  (camera_utils.py:22)                */
+    double t[3];                  /* camera translation       (camera_utils.py:21)                */
+    double plane_pt[F3D_NPLANES][3];   /* fusion.py:254-257                                       */
+    double plane_n[F3D_NPLANES][3];    /* inward normals, fusion.py:256-258                       */
+    double plane_off[F3D_NPLANES];     /* n . plane_pt, only used by the conservative pre-cull    */
+    double cull_rel;              /* pre-cull margin = cull_rel * (|x|+|y|+|z|) + cull_abs: a point  */
+    double cull_abs;              /* closer than that to a plane is decided by the exact plane test */
+} f3d_view;
+
+/* An oriented box as open3d's OrientedBoundingBox exposes it (center, R columns = axes, extent);
+ * merge_intersecting_bb.py:75-76. */
+typedef struct f3d_obb {
+    double center[3];
+    double R[9];                  /* row-major 3x3, column i = axis i                             */
+    double extent[3];
+} f3d_obb;
+
+typedef struct f3d_ctx f3d_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int         f3d_version(void);
+f3d_ctx*    f3d_ctx_create(int device);            /* NULL on failure (no device, HIP error)      */
+void        f3d_ctx_destroy(f3d_ctx* ctx);
+const char* f3d_last_error(const f3d_ctx* ctx);    /* ctx may be NULL: last creation error        */
+int         f3d_ctx_synchronize(f3d_ctx* ctx);
+void*       f3d_ctx_stream(f3d_ctx* ctx);          /* the context's hipStream_t                   */
+
+/* ---- host-side geometry (tiny, per view; no device needed) ------------------------------ */
+/* pyquaternion Quaternion(q).inverse.elements at camera_utils.py:22 */
+int f3d_quat_inverse(const double q_wxyz[4], double qinv_wxyz[4]);
+/* Fusion._get_frustum_data (fusion.py:119-132; camera_utils.py:60-171), frame_ids = all.
+ * eyes [V,3], lookats [V,3], face_normals [V,4,3]; any output may be NULL. */
+int f3d_frustum_data(const double K[9], double w, double h, const double* q_wxyz /*[V,4]*/,
+                     const double* t /*[V,3]*/, int nviews,
+                     double* eyes, double* lookats, double* face_normals);
+/* The packed per-view records: K, inverse pose, and the 5 planes Fusion.fuse builds per frame
+ * (fusion.py:254-258) with far plane at eye + max_depth * lookat. */
+int f3d_views_build(const double K[9], double w, double h, const double* q_wxyz, const double* t,
+                    int nviews, double max_depth, f3d_view* out /*[V]*/);
+
+/* ---- a1: SpatQuadranion.rotate (RTAB_utils/spatQuad.py:7-28) ----------------------------- */
+int f3d_rotate_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double q_wxyz[4], double* out);
+
+/* ---- a2: points2pixel (Fusion3DSeg/camera_utils.py:9-26) -> int32 uv[2*n], row 0 = u ------ */
+int f3d_points2pixel_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double K[9],
+                         const double q_wxyz[4], const double t[3], int32_t* uv);
+int f3d_points2pixel_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                         const double K[9], const double q_wxyz[4], const double t[3],
+                         int32_t* uv, void* stream);
+
+/* ---- a4: point_inside_polyhedra (Fusion3DSeg/intersections.py:146-164) -> uint8 inside[n] - */
+int f3d_inside_polyhedra_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double* plane_pts,
+                             const double* normals, int m, uint8_t* inside);
+int f3d_inside_polyhedra_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                             const double* plane_pts /*host [m,3]*/, const double* normals /*host*/,
+                             int m, uint8_t* inside, void* stream);
+
+/* ---- a2+a4 fused for one view: the per-frame body of Fusion.fuse (fusion.py:254-266) ------ */
+/* uv is written for every point (like points2pixel), inside as a4. */
+int f3d_project_view_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const f3d_view* view /*host*/,
+                         int32_t* uv, uint8_t* inside);
+int f3d_project_view_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                         const f3d_view* view /*host*/, int32_t* uv, uint8_t* inside, void* stream);
+
+/* ---- fused multi-view path: project -> sample -> vote -> segment ------------------------- */
+/* For every point and view: inside (a4) -> uv (a2) -> drop u not in [0,W) or v not in [0,H) ->
+ * label = masks[v][row][col] -> one vote; then VotingSegmentation.segment (voting.py:106-137)
+ * with `nclasses`, `threshold`, optional `filter` (NULL / 0 = none).
+ * classes: int64 [n].  votes_u16 (optional, may be NULL): uint16 [n, nclasses+1] vote counts,
+ * equal to the reference's float64 votes matrix on this path.
+ * Labels > nclasses make the reference raise IndexError -> F3D_ERR_INDEX (host variant; the
+ * _dev variant records it, fetch with f3d_take_device_error after synchronising). */
+int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                            const f3d_view* views, int nviews,
+                            const uint8_t* masks /*[V,H,W]*/, int h, int w,
+                            int nclasses, const int32_t* filter, int nfilter, double threshold,
+                            int64_t* classes, uint16_t* votes_u16);
+int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                                const f3d_view* views_dev /*device [V]*/, int nviews,
+                                const uint8_t* masks, int h, int w,
+                                int nclasses, const int32_t* filter /*host*/, int nfilter,
+                                double threshold, int64_t* classes, uint16_t* votes_u16,
+                                void* stream);
+/* Returns and clears the sticky error recorded by _dev kernels of this context
+ * (F3D_OK or F3D_ERR_INDEX).  Synchronises the context's error word only. */
+int f3d_take_device_error(f3d_ctx* ctx, void* stream);
+
+/* ---- a7: one frame of VotingSegmentation.vote (voting.py:94-98) --------------------------- */
+/* votes[uv2pt[i], mask[i]] += 1 for uv2pt[i] != -1, each distinct (point,label) pair of the
+ * frame counted once (quirk Q1).  votes: float64 [npts, ncols], updated in place. */
+int f3d_vote_uv2pt(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int64_t hw,
+                   double* votes, int64_t npts, int ncols);
+int f3d_vote_uv2pt_dev(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int64_t hw,
+                       double* votes, int64_t npts, int ncols, void* stream);
+
+/* ---- a8: VotingSegmentation.segment (voting.py:106-137) ----------------------------------- */
+int f3d_segment_votes(f3d_ctx* ctx, const double* votes, int64_t npts, int ncols, int nclasses,
+                      double threshold, const int32_t* filter, int nfilter, int64_t* classes);
+int f3d_segment_votes_dev(f3d_ctx* ctx, const double* votes, int64_t npts, int ncols, int nclasses,
+                          double threshold, const int32_t* filter /*host*/, int nfilter,
+                          int64_t* classes, void* stream);
+
+/* ---- a9: mask post-processing of SegmentImage (get2DSeg.py:110-118) ----------------------- */
+/* sem: float32 [c, hw] logits -> uint8 mask[hw]: argmax over c; softmax max < conf -> `low`. */
+int f3d_sem_logits_to_mask(f3d_ctx* ctx, const float* sem, int c, int64_t hw, float conf_threshold,
+                           int low_label, uint8_t* mask);
+int f3d_sem_logits_to_mask_dev(f3d_ctx* ctx, const float* sem, int c, int64_t hw,
+                               float conf_threshold, int low_label, uint8_t* mask, void* stream);
+
+/* ---- a10/a11: oriented-box membership for merge_bb (merge_intersecting_bb.py:64-91) ------- */
+/* inside_bits: uint32 [n, ceil(b/32)] -- bit k of word j of point i set iff point i lies in box
+ * 32*j+k (|Rt(p-c)|_a <= extent_a/2, a = 0..2).  cooc (optional): uint8 [b,b], cooc[i][j] = 1 iff
+ * some point lies in both boxes i and j ("index lists share an element", :64-66,88-90). */
+int f3d_points_in_obb(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                      const f3d_obb* boxes, int b, uint32_t* inside_bits, uint8_t* cooc);
+int f3d_points_in_obb_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                          const f3d_obb* boxes /*host*/, int b, uint32_t* inside_bits,
+                          uint8_t* cooc /*device, zeroed by the call*/, void* stream);
+/* update_id_info's relabel (merge_intersecting_bb.py:59-61): ids[ids == from] = to; returns the
+ * number of relabelled points through *count (may be NULL). */
+int f3d_relabel(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to, int64_t* count);
+int f3d_relabel_dev(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
+                    int64_t* count_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F3D_H */

@@ -1,0 +1,174 @@
+"""Parity of the HIP path (through the C-ABI, via ctypes) against the oracle and the golden vectors.
+Needs a real MI355X: run with `-m gpu`.  Integer outputs (labels, uv, inside, votes) are compared
+bit for bit with the oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import f3d
+from f3d import synth
+from oracle import np_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    return f3d.default_context()
+
+
+def test_rotate_bit_exact(ctx, golden):
+    g = golden('rotate')
+    for q in g['q_wxyz']:
+        assert np.array_equal(ctx.rotate(g['points'], q), O.rotate(q, g['points']))
+    assert ctx.rotate(np.zeros((0, 3)), g['q_wxyz'][0]).shape == (0, 3)
+
+
+def test_points2pixel_vs_oracle_and_golden(ctx, golden):
+    g = golden('points2pixel')
+    flips = total = 0
+    for ki, K in enumerate(g['K']):
+        for j, (q, t) in enumerate(zip(g['q_wxyz'], g['t'])):
+            got = ctx.points2pixel(g['points'], K, q, t)
+            assert got.dtype == np.int32 and got.shape == (2, len(g['points']))
+            assert np.array_equal(got, O.points2pixel(g['points'], K, q, t))        # bit-exact vs oracle
+            want = g['uv'][ki, j]
+            ok = (np.abs(want.astype(np.int64)) < 2 ** 30).all(0)
+            d = np.abs(got.astype(np.int64) - want)[:, ok]
+            assert d.max() <= 1                                                     # stated uv tolerance vs reference
+            flips += int((d != 0).sum()); total += d.size
+    assert flips <= int(1e-6 * total)
+
+
+def test_points2pixel_degenerate_inputs(ctx):
+    K = synth.CALIB_K
+    q, t = np.array([1., 0, 0, 0]), np.zeros(3)
+    pts = np.array([[0., 0, 0], [1, 1, 0], [1e300, 1, 1e-300], [np.nan, 0, 1], [0.5, 0.25, 1.0], [-3., 2., -1.]])
+    with np.errstate(all='ignore'):
+        want = O.points2pixel(pts, K, q, t)
+    assert np.array_equal(ctx.points2pixel(pts, K, q, t), want)                     # z = 0 / NaN -> INT32_MIN
+    with pytest.raises(ZeroDivisionError):
+        ctx.points2pixel(pts, K, np.zeros(4), t)
+
+
+def test_inside_polyhedra_bit_exact_incl_near_plane(ctx, golden):
+    g = golden('inside_polyhedra')
+    for j in range(len(g['plane_points'])):
+        got = ctx.inside_polyhedra(g['points'], g['plane_points'][j], g['plane_normals'][j])
+        assert got.dtype == np.bool_ and np.array_equal(got, g['inside'][j])
+        got = ctx.inside_polyhedra(g['adv_points'], g['plane_points'][j], g['plane_normals'][j])
+        assert np.array_equal(got, g['inside_adv'][j])
+    # more planes than one launch carries (chained launches), and the empty plane list
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, (3000, 3))
+    nr = rng.normal(size=(40, 3)); pp = -0.9 * nr / np.linalg.norm(nr, axis=1)[:, None]
+    assert np.array_equal(ctx.inside_polyhedra(pts, pp, nr), O.point_inside_polyhedra(pts, pp, nr))
+    assert ctx.inside_polyhedra(pts, np.zeros((0, 3)), np.zeros((0, 3))).all()
+
+
+def test_project_view_single_view_fused(ctx):
+    sc = synth.scene('C2', n=20000)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    ppts, pnrm = O.frustum_planes(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    for j in (0, 7):
+        uv, ins = ctx.project_view(sc['points'], views[j])
+        assert np.array_equal(uv, O.points2pixel(sc['points'], sc['K'], sc['wxyzs'][j], sc['translations'][j]))
+        assert np.array_equal(ins, O.point_inside_polyhedra(sc['points'], ppts[j], pnrm[j]))
+        assert 0.05 < ins.mean() < 0.95
+
+
+@pytest.mark.parametrize('mask_kind', ['block64', 'iid'])
+@pytest.mark.parametrize('thr,flt', [(0.5, None), (0.0, None), (0.5, [86, 114, 115]), (0.3, [115, 0, 86]),
+                                     (0.2, [3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 120, 15, 133, 132, 86, 114])])
+def test_fused_forward_labels_and_votes_bit_exact(ctx, mask_kind, thr, flt):
+    sc = synth.scene('C1', n=30000, mask_kind=mask_kind)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    want_cls, want_votes = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'],
+                                                 sc['max_depth'], 133, thr, flt, return_votes=True)
+    got = ctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, thr, flt)
+    assert got.dtype == np.int64 and np.array_equal(got, want_cls)
+    got2, votes = ctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, thr, flt, return_votes=True)
+    assert np.array_equal(got2, want_cls)
+    assert np.array_equal(votes.astype(np.float64), want_votes)
+    assert want_votes.sum() > 0.2 * len(sc['points'])
+    # float32 storage of the same cloud gives the same labels (points are f32-representable)
+    got32 = ctx.project_vote_argmax(sc['points'].astype(np.float32), views, sc['masks'], 133, thr, flt)
+    assert np.array_equal(got32, want_cls)
+
+
+def test_fused_forward_many_views_uint16_bins(ctx):
+    rng = np.random.default_rng(3)
+    V, h, w = 300, 64, 64
+    K = np.array([[50., 0, 32], [0, 50., 32], [0, 0, 1]])
+    q, t = synth.ring_views(V)
+    pts = synth.cloud(5000)
+    masks = np.full((V, h, w), 86, np.uint8)                      # every visible view votes 86: counts > 255
+    masks[::7] = rng.integers(0, 134, (len(masks[::7]), h, w), dtype=np.uint8)
+    views = f3d.views_build(K, w, h, q, t, 10.0)
+    want, wv = O.project_vote_argmax(pts, K, q, t, masks, 10.0, 133, 0.5, None, return_votes=True)
+    got, gv = ctx.project_vote_argmax(pts, views, masks, 133, 0.5, None, return_votes=True)
+    assert wv.max() > 255
+    assert np.array_equal(got, want) and np.array_equal(gv.astype(np.float64), wv)
+    assert np.array_equal(ctx.project_vote_argmax(pts, views, masks, 133, 0.5, None), want)
+
+
+def test_fused_forward_edge_cases(ctx):
+    sc = synth.scene('C1', n=1000)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    assert ctx.project_vote_argmax(np.zeros((0, 3)), views, sc['masks']).shape == (0,)
+    # points exactly on planes / at the eye: the exact plane test decides
+    eye = sc['translations'][0]
+    pts = np.vstack([eye, eye + 1e-13, sc['points'][:50], [[np.nan, 0, 0]], [[np.inf, 0, 0]], [[1e308, 1e308, 1e308]]])
+    with np.errstate(all='ignore'):
+        want = O.project_vote_argmax(pts, sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'])
+    assert np.array_equal(ctx.project_vote_argmax(pts, views, sc['masks']), want)
+    # a label beyond nclasses raises IndexError like voting.py:98
+    bad = sc['masks'].copy(); bad[:] = 200
+    with pytest.raises(IndexError):
+        ctx.project_vote_argmax(sc['points'], views, bad, nclasses=133)
+    with pytest.raises(IndexError):
+        ctx.project_vote_argmax(sc['points'], views, sc['masks'], nclasses=133, filter_classes=[86, 134])
+
+
+def test_vote_uv2pt_q1_and_segment_golden(ctx, golden):
+    g = golden('voting')
+    ncls = int(g['nclasses'])
+    votes = np.zeros_like(g['votes'])
+    for mask, lut in zip(g['masks'], g['uv2pt']):
+        ctx.vote_uv2pt(votes, lut, mask.reshape(-1))
+    assert np.array_equal(votes, g['votes'])
+    for i in range(int(g['nseg'])):
+        flt = g[f'seg{i}_filter'].tolist() if g[f'seg{i}_has_filter'] else None
+        got = ctx.segment_votes(g['votes'], ncls, float(g[f'seg{i}_threshold']), flt)
+        assert got.dtype == np.int64 and np.array_equal(got, g[f'seg{i}_classes']), i
+    assert np.array_equal(ctx.segment_votes(g['votes'], g['votes'].shape[1], 0.75, None), g['segq2_classes'])   # Q2
+    for i in range(int(g['nsmall'])):                                # odd column count -> scalar-load path
+        flt = g[f'small{i}_filter'].tolist() if g[f'small{i}_has_filter'] else None
+        got = ctx.segment_votes(g['small_votes'], 4, float(g[f'small{i}_threshold']), flt)
+        assert np.array_equal(got, g[f'small{i}_classes']), i
+
+
+def test_vote_uv2pt_errors_leave_votes_untouched(ctx):
+    votes = np.zeros((4, 3))
+    with pytest.raises(IndexError):
+        ctx.vote_uv2pt(votes, np.array([0, 1], np.int32), np.array([0, 3], np.uint8))
+    with pytest.raises(IndexError):
+        ctx.vote_uv2pt(votes, np.array([1, 4], np.int32), np.array([0, 0], np.uint8))
+    assert votes.sum() == 0
+    ctx.vote_uv2pt(votes, np.array([-2, -1, 2, 2], np.int32), np.array([1, 1, 1, 2], np.uint8))
+    assert votes[2, 1] == 1 and votes[2, 2] == 1 and votes.sum() == 2
+
+
+def test_vote_and_segment_larger_random(ctx):
+    rng = np.random.default_rng(11)
+    npts, hw, ncols = 20000, 192 * 256, 134
+    votes = np.zeros((npts, ncols)); want = np.zeros((npts, ncols))
+    for f in range(6):
+        lut = rng.integers(-1, npts, hw).astype(np.int32)
+        lut[rng.random(hw) < 0.4] = -1
+        lut[1000:3000] = lut[1000]                                   # heavy duplication
+        mask = rng.choice(synth.ALPHABET, hw)
+        ctx.vote_uv2pt(votes, lut, mask)
+        O.vote_frame(want, lut, mask)
+    assert np.array_equal(votes, want)
+    for thr, flt in [(0.5, None), (0.5, [86, 114, 115]), (0.1, list(range(100, 134)))]:
+        assert np.array_equal(ctx.segment_votes(votes, 133, thr, flt), O.segment(want, 133, thr, flt))
