@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: labelled points / second of the fused Fusion3DSeg hot path on MI355X.
+
+One step = one pass of the hot path over one batch: every point of the rank's cloud shard is
+projected into all V views, sampled, voted and segmented (f3d_project_vote_argmax_dev), with the
+inputs already resident in HBM.  Workload at N=1: BASELINE.json config C3 (10M points x 64 views,
+1024x1024 masks).  With N>1 ranks (torchrun, one per GPU) every rank owns a 10M-point shard of an
+N x 10M cloud and the V/N views whose masks it "produced"; each step all-gathers the masks over
+RCCL (the path's one exchange step) and then fuses its shard -- weak scaling.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--filter] [--masks iid|block64]
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+PKG = ROOT / '3d-point-cloud-segmentation-using-2d-img-segmentation_amd'
+for _p in (str(ROOT), str(PKG)):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+FP64_VALU_PEAK_TFLOPS = 78.6     # vector fp64 (FMA = 2 flop)
+FLOP_PER_POINT_VIEW = 82         # algorithmic fp64 flop of frustum + projection
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--points', type=int, default=10_000_000, help='points per GPU (C3: 10M)')
+    ap.add_argument('--views', type=int, default=64)
+    ap.add_argument('--size', type=int, default=1024, help='mask width = height')
+    ap.add_argument('--masks', default='block64', choices=['block64', 'iid'])
+    ap.add_argument('--filter', action='store_true', help='segment with the reference default filter_classes=[86,114,115]')
+    ap.add_argument('--f32', action='store_true', help='store xyz as float32 (12 B/point) instead of float64')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the streaming-kernel measurements')
+    ap.add_argument('--cpu-sample', type=int, default=100_000)
+    ap.add_argument('--sorted', action='store_true', help='experiment: store the cloud in spatially sorted (grid-cell) order')
+    return ap.parse_args()
+
+
+def algorithmic_bytes(n, v, h, w, xyz_bytes):
+    """xyz read once + masks read once + int64 classes written + view records."""
+    return xyz_bytes * n + v * h * w + 8 * n + 424 * v
+
+
+def time_kernel(torch, fn, iters, stream):
+    """Average device time of fn() over `iters` launches, HIP events on the launch stream."""
+    fn(); stream.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(iters):
+        fn()
+    b.record(stream)
+    b.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def cpu_baseline(sample, views_n, size, mask_kind, filter_classes):
+    """The NumPy port of the reference path (oracle/np_ref.py) on a bounded slice of the same workload."""
+    from f3d import synth
+    from oracle import np_ref as O
+    K = np.array([[800., 0, size / 2], [0, 800., size / 2], [0, 0, 1]])
+    q, t = synth.ring_views(views_n)
+    pts = synth.cloud(sample)
+    masks = synth.masks(views_n, size, size, mask_kind)
+    t0 = time.perf_counter()
+    cls = O.project_vote_argmax(pts, K, q, t, masks, 10.0, 133, 0.5, filter_classes)
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit='points/s', cores=1, kind='port',
+                sample=f'{sample} points x {views_n} views ({dt:.1f} s, single NumPy process, '
+                       f'{os.cpu_count()} host cpus visible); linear in N, so points/s carries over to 10M'), cls, pts, masks
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import f3d
+    from f3d import synth
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback on the product path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    ctx = f3d.Context(local)
+
+    n, V, S = args.points, args.views, args.size
+    flt = [86, 114, 115] if args.filter else None
+    K = np.array([[800., 0, S / 2], [0, 800., S / 2], [0, 0, 1]])
+    q, t = synth.ring_views(V)
+    views_np = f3d.views_build(K, S, S, q, t, 10.0)
+    xyz_np = synth.cloud(n, dtype=np.float32 if args.f32 else np.float64, shard=rank)
+    if args.sorted:
+        cell = np.floor((xyz_np.astype(np.float64) - np.array([-5, -5, 0])) / 0.25).astype(np.int64)
+        xyz_np = xyz_np[np.argsort((cell[:, 0] * 64 + cell[:, 1]) * 16 + cell[:, 2], kind='stable')]
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    del xyz_np
+    masks_np = synth.masks(V, S, S, args.masks)
+    views = torch.from_numpy(views_np).to(dev)
+    masks_full = torch.empty((V, S, S), dtype=torch.uint8, device=dev)
+    if world > 1:
+        if V % world:
+            raise SystemExit(f'--views {V} must be divisible by the world size {world}')
+        per = V // world
+        masks_shard = torch.from_numpy(masks_np[rank * per:(rank + 1) * per]).to(dev)
+    else:
+        masks_full.copy_(torch.from_numpy(masks_np))
+    classes = torch.empty(n, dtype=torch.int64, device=dev)
+    dtype = f3d.F32 if args.f32 else f3d.F64
+    stream = torch.cuda.Stream(dev)          # a real (non-null) HIP stream: kernels, RCCL and the timing events all use it
+    torch.cuda.set_stream(stream)
+
+    def fuse():
+        ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, masks_full.data_ptr(), S, S,
+                                    133, 0.5, flt, classes.data_ptr(), None, stream.cuda_stream)
+
+    def step():
+        if world > 1:
+            dist.all_gather_into_tensor(masks_full.view(-1), masks_shard.view(-1))
+        fuse()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ctx.take_device_error(stream.cuda_stream)
+
+    # dominant kernel alone, HIP events on its launch stream (same resident inputs)
+    k_iters = max(3, min(args.steps, 10))
+    t_kernel = time_kernel(torch, fuse, k_iters, stream)
+    xyz_b = 12 if args.f32 else 24
+    abytes = algorithmic_bytes(n, V, S, S, xyz_b)
+    achieved = abytes / t_kernel / 1e9
+    roofline = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    kernel='k_fuse', kernel_ms=round(t_kernel * 1e3, 4), algorithmic_bytes=abytes,
+                    valu_frac=round(FLOP_PER_POINT_VIEW * n * V / t_kernel / (FP64_VALU_PEAK_TFLOPS * 1e12), 4),
+                    note='fused V-view kernel is fp64-VALU / gather bound (SURVEY 8(d)): HBM fraction ceiling ~7%; '
+                         'valu_frac = 82 flop x N x V / t / 78.6 TF')
+
+    out = None
+    if rank == 0:
+        total_points = n * world
+        out = dict(metric='labelled points/sec (10M pts x 64 views) at 1/2/4/8 GPU; % HBM roofline',
+                   value=round(total_points * args.steps / elapsed, 1), unit='points/s', n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+                   config=dict(workload=f'C3: {n} points/GPU x {V} ring views, {S}x{S} {args.masks} uint8 masks, '
+                                        f'nclasses=133, threshold=0.5, filter_classes={flt}; fused project->sample->vote->segment',
+                               points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64',
+                               exchange='none' if world == 1 else f'RCCL all_gather of {V // world} masks/rank each step'),
+                   roofline=roofline)
+
+    # secondary, HBM-streaming kernels of the same path (not part of `value`)
+    if rank == 0 and not args.no_extras:
+        extras = {}
+        uv = torch.empty((2, n), dtype=torch.int32, device=dev)
+        ins = torch.empty(n, dtype=torch.uint8, device=dev)
+        tk = time_kernel(torch, lambda: ctx.project_view_dev(xyz.data_ptr(), dtype, n, views_np[0], uv.data_ptr(), ins.data_ptr(),
+                                                             stream.cuda_stream), 10, stream)
+        b = (xyz_b + 8 + 1) * n
+        extras['project_view (a2+a4, 1 view)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                                        bytes_per_point=xyz_b + 9)
+        del uv, ins
+        ns = min(n, 4_000_000)
+        votes = torch.zeros((ns, 134), dtype=torch.float64, device=dev)
+        votes.view(-1)[::7] = 3.0
+        cls2 = torch.empty(ns, dtype=torch.int64, device=dev)
+        tk = time_kernel(torch, lambda: ctx.segment_votes_dev(votes.data_ptr(), ns, 134, 133, 0.5, None, cls2.data_ptr(), stream.cuda_stream), 10, stream)
+        b = (134 * 8 + 8) * ns
+        extras['segment_votes (a8)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                             bytes_per_point=1080, points=ns)
+        del votes, cls2
+        out['streaming_kernels'] = extras
+
+    if rank == 0 and not args.no_cpu_baseline:
+        cb, cls_cpu, pts_cpu, masks_cpu = cpu_baseline(args.cpu_sample, V, S, args.masks, flt)
+        out['cpu_baseline'] = cb
+        # the same sample through the HIP path must give the same labels
+        got = f3d.default_context(local).project_vote_argmax(pts_cpu, views_np, masks_cpu, 133, 0.5, flt)
+        out['parity_on_cpu_sample'] = bool(np.array_equal(got, cls_cpu))
+    elif rank == 0:
+        out['cpu_baseline'] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
