@@ -12,11 +12,14 @@
 #include "f3d_kernels.h"
 #include "f3d_math.h"
 
+static_assert(sizeof(f3d_view) == 640, "f3d_view is 80 doubles");
+
 #pragma clang fp contract(off)
 
 namespace {
 
-enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_COUNT };
+enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_SORT_PERM, SLOT_SORT_SCRATCH,
+       SLOT_COUNT };
 
 thread_local char g_create_err[512] = "";
 
@@ -262,23 +265,42 @@ int f3d_views_build(const double K[9], double w, double h, const double* q, cons
             vw->plane_pt[4][c] = fr.eye[c] + max_depth * fr.lookat[c];
             vw->plane_n[4][c] = -fr.lookat[c];
         }
-        double l1max = 0.0;
+        double l1max = 0.0, nmax = 1.0;
         for (int m = 0; m < F3D_NPLANES; ++m) {
-            vw->plane_off[m] = fma(vw->plane_n[m][0], vw->plane_pt[m][0],
-                               fma(vw->plane_n[m][1], vw->plane_pt[m][1], vw->plane_n[m][2] * vw->plane_pt[m][2]));
             const double nl1 = fabs(vw->plane_n[m][0]) + fabs(vw->plane_n[m][1]) + fabs(vw->plane_n[m][2]);
             const double l1 = (fabs(vw->plane_pt[m][0]) + fabs(vw->plane_pt[m][1]) + fabs(vw->plane_pt[m][2])) * (nl1 > 1 ? nl1 : 1);
             if (l1 > l1max) l1max = l1;
-        }
-        // both the pre-cull value and the exact dot product are within ~12 eps * (|p|_1 + |pp|_1) of the
-        // real number n.(p - pp); 64 eps leaves a 5x margin (|n|_inf <= 1 for unit normals; non-unit
-        // normals are covered by the nl1 factor above and by cull_rel scaling below)
-        const double eps64 = 64.0 * 2.220446049250313e-16;
-        double nmax = 1.0;
-        for (int m = 0; m < F3D_NPLANES; ++m)
             for (int c = 0; c < 3; ++c) if (fabs(vw->plane_n[m][c]) > nmax) nmax = fabs(vw->plane_n[m][c]);
-        vw->cull_rel = eps64 * nmax;
-        vw->cull_abs = eps64 * l1max + 1e-300;
+        }
+        // float32 pre-cull a = n32.p32 - off32: inputs rounded to f32 (2^-24 relative each) + 3 f32 FMAs, against the
+        // exact plane value that itself carries ~12 eps64 of rounding: 32 * 2^-24 * (|p|_1 + |pp|_1) covers both, 2x margin
+        const double eps32 = 32.0 * 5.9604644775390625e-08;
+        for (int m = 0; m < F3D_NPLANES; ++m) {
+            for (int c = 0; c < 3; ++c) vw->cull_n32[m][c] = (float)vw->plane_n[m][c];
+            const double off = fma(vw->plane_n[m][0], vw->plane_pt[m][0],
+                               fma(vw->plane_n[m][1], vw->plane_pt[m][1], vw->plane_n[m][2] * vw->plane_pt[m][2]));
+            vw->cull_off32[m] = (float)off;
+        }
+        vw->cull_rel32 = (float)(eps32 * nmax * 1.0000002);
+        vw->cull_abs32 = (float)(eps32 * l1max * 1.0000002 + 1e-30);
+        // fast projection operator M = K * Rot(qinv), Rot = the matrix of x -> q x q* for the un-normalised q
+        {
+            const long double w_ = vw->qinv[0], x = vw->qinv[1], y = vw->qinv[2], z = vw->qinv[3];
+            const long double R[9] = {w_ * w_ + x * x - y * y - z * z, 2 * (x * y - w_ * z), 2 * (x * z + w_ * y),
+                                      2 * (x * y + w_ * z), w_ * w_ - x * x + y * y - z * z, 2 * (y * z - w_ * x),
+                                      2 * (x * z - w_ * y), 2 * (y * z + w_ * x), w_ * w_ - x * x - y * y + z * z};
+            const long double q2 = w_ * w_ + x * x + y * y + z * z;
+            for (int r = 0; r < 3; ++r) {
+                long double l1 = 0;
+                for (int c = 0; c < 3; ++c) {
+                    long double acc = 0;
+                    for (int k = 0; k < 3; ++k) acc += (long double)K[3 * r + k] * R[3 * k + c];
+                    vw->M[3 * r + c] = (double)acc;
+                    l1 += fabsl((long double)K[3 * r + c]);
+                }
+                vw->mnorm[r] = (double)(l1 * q2 * 1.000000001L);
+            }
+        }
     }
     return F3D_OK;
 }
@@ -391,19 +413,59 @@ int f3d_inside_polyhedra_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const d
 // ---------------------------------------------------------------------------------------------
 // fused multi-view path
 // ---------------------------------------------------------------------------------------------
+int f3d_cloud_sort_cells_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, void* sorted_xyz, int32_t* perm,
+                             void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || n > 0x7fffffffLL || (n > 0 && (!xyz || !sorted_xyz || !perm)))
+        return fail(ctx, F3D_ERR_INVALID, "cloud_sort_cells: bad arguments (n < 2^31)");
+    if (n == 0) return F3D_OK;
+    void* scratch;
+    if ((rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &scratch))) return rc;   // grows on first use only
+    F3D_HIP(ctx, f3d_launch_cell_sort(xyz, dtype, n, sorted_xyz, perm, scratch, pick(ctx, stream)));
+    return F3D_OK;
+}
+
 int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews,
                                 const uint8_t* masks, int h, int w, int nclasses, const int32_t* filter, int nfilter,
-                                double threshold, int64_t* classes, uint16_t* votes_u16, void* stream) {
+                                double threshold, int64_t* classes, uint16_t* votes_u16, unsigned flags, const int32_t* perm,
+                                void* stream) {
     int rc = enter(ctx); if (rc) return rc;
     if (n < 0 || nviews < 0 || h <= 0 || w <= 0 || nclasses < 0 || nclasses > 65534 || !classes ||
         (n > 0 && !xyz) || (nviews > 0 && (!views_dev || !masks)))
         return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: bad arguments");
     if (nviews > 65535) return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: at most 65535 views");
+    if ((flags & F3D_FUSE_SORT) && perm) return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: F3D_FUSE_SORT and perm are exclusive");
     hipStream_t s = pick(ctx, stream);
     f3d_filter_args fa;
     if ((rc = make_filter(ctx, filter, nfilter, nclasses + 1, true, s, &fa))) return rc;
+    bool gather = false;
+    if ((flags & F3D_FUSE_SORT) && n > 512 && n <= 0x7fffffffLL) {
+        void *sperm, *scratch;                                                                  // grow on first use only
+        if ((rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &sperm))) return rc;
+        if ((rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &scratch))) return rc;
+        F3D_HIP(ctx, f3d_launch_cell_sort(xyz, dtype, n, nullptr, (int32_t*)sperm, scratch, s));
+        perm = (const int32_t*)sperm; gather = true;                                            // the kernel reads xyz[perm[i]]
+    }
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, h, w, nclasses, fa, threshold, classes, votes_u16,
-                                 ctx->dev_err, 0, s));
+                                 ctx->dev_err, perm, gather, s));
+    return F3D_OK;
+}
+
+int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views, int nviews,
+                             uint64_t stats[4]) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || nviews < 0 || !stats || (n > 0 && !xyz) || (nviews > 0 && !views))
+        return fail(ctx, F3D_ERR_INVALID, "fastpath_audit: bad arguments");
+    void *dxyz, *dviews, *dstats;
+    if ((rc = ensure(ctx, SLOT_XYZ, xyz_bytes(dtype, n), &dxyz))) return rc;
+    if ((rc = ensure(ctx, SLOT_VIEWS, sizeof(f3d_view) * (size_t)nviews, &dviews))) return rc;
+    if ((rc = ensure(ctx, SLOT_AUX0, 64, &dstats))) return rc;
+    hipStream_t s = ctx->stream;
+    if (n) F3D_HIP(ctx, hipMemcpyAsync(dxyz, xyz, xyz_bytes(dtype, n), hipMemcpyHostToDevice, s));
+    if (nviews) F3D_HIP(ctx, hipMemcpyAsync(dviews, views, sizeof(f3d_view) * (size_t)nviews, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, f3d_launch_fastpath_audit(dxyz, dtype, n, (const f3d_view*)dviews, nviews, (unsigned long long*)dstats, s));
+    F3D_HIP(ctx, hipMemcpyAsync(stats, dstats, 32, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
     return F3D_OK;
 }
 
@@ -432,8 +494,11 @@ int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
         F3D_HIP(ctx, hipMemcpyAsync(dviews, views, sizeof(f3d_view) * (size_t)nviews, hipMemcpyHostToDevice, s));
         F3D_HIP(ctx, hipMemcpyAsync(dmasks, masks, mbytes, hipMemcpyHostToDevice, s));
     }
+    // NumPy callers hand over clouds in arbitrary order: cell-sort large ones (results are order-independent)
+    const unsigned flags = n >= 65536 ? F3D_FUSE_SORT : 0u;
     if ((rc = f3d_project_vote_argmax_dev(ctx, dxyz, dtype, n, (const f3d_view*)dviews, nviews, (const uint8_t*)dmasks, h, w,
-                                          nclasses, filter, nfilter, threshold, (int64_t*)dcls, (uint16_t*)dvotes, s)))
+                                          nclasses, filter, nfilter, threshold, (int64_t*)dcls, (uint16_t*)dvotes, flags,
+                                          nullptr, s)))
         return rc;
     if ((rc = take_error(ctx, s))) return rc;
     F3D_HIP(ctx, hipMemcpyAsync(classes, dcls, (size_t)n * 8, hipMemcpyDeviceToHost, s));

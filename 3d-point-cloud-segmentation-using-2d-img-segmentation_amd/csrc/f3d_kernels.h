@@ -7,6 +7,14 @@
 #define F3D_DEVERR_INDEX 1                 // sticky device error bit: the reference would raise IndexError
 #define F3D_PLANES_PER_LAUNCH 16
 #define F3D_OBB_MAX_BOXES 4096
+#define F3D_SORT_MAX_CELLS 32767            // + 1 overflow cell = 2^15 keys -> 16 key bits sorted
+
+struct f3d_cellgrid {                      // device-resident description of the cell-sort grid
+    double lo[3];
+    double inv_cell;
+    int dim[3];
+    int ncells;                            // dim[0]*dim[1]*dim[2] + 1 (last cell: non-finite points)
+};
 
 struct f3d_plane_args {                    // by-value kernel argument of k_inside_polyhedra
     int m;
@@ -28,9 +36,19 @@ hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, co
                                        hipStream_t s);
 size_t f3d_fuse_lds_bytes(int mode, int nclasses);
 int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
+// perm (device, may be NULL): caller-order index of sorted point i.  gather_xyz = false: xyz is already the sorted copy;
+// gather_xyz = true: xyz is the caller's cloud and the kernel reads point perm[i]
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, int grid_blocks, hipStream_t s);
+                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, hipStream_t s);
+// audit of the fast projection (tests only): for every (point, view) pair inside the frustum counts
+// stats[0] pairs, stats[1] pairs sent to the exact fallback, stats[2] accepted pairs whose floor differs from the
+// canonical path (must stay 0), stats[3] pairs rejected/accepted by the f32 cull that the exact test contradicts (0)
+hipError_t f3d_launch_fastpath_audit(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                                     unsigned long long* stats_dev, hipStream_t s);
+// cell sort (f3d_sort.hip): perm (and sorted_xyz unless NULL) receive the cloud in grid-cell order; scratch >= f3d_sort_scratch_bytes(n)
+size_t f3d_sort_scratch_bytes(int64_t n);
+hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sorted_xyz, int32_t* perm, void* scratch, hipStream_t s);
 hipError_t f3d_launch_segment_votes(const double* votes, int64_t npts, int ncols, int nclasses, double threshold,
                                     const f3d_filter_args& flt, int64_t* classes, hipStream_t s);
 hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols,

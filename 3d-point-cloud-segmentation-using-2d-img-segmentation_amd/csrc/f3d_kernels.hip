@@ -5,6 +5,8 @@
 // the per-view camera records, LDS vote histograms and ≫256 workgroups per launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "f3d.h"
 #include "f3d_math.h"
 #include "f3d_kernels.h"
@@ -69,23 +71,29 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_inside_polyhedra(const T* __restr
 // ------------------------------------------------------------------------------------------
 // fused multi-view kernel: project -> sample -> vote -> segment.
 //
-// One thread owns one point for a tile of 256 points; it keeps xyz in registers and walks the V
-// views.  The view record (53 doubles) is read through scalar loads (wave-uniform address), so the
-// fp64 VALU instructions take it from SGPRs and no LDS/VGPR is spent on it.
+// One thread owns one point of a 256-point tile (4 wavefronts of 64 consecutive points) and keeps
+// its xyz in registers.  Results are exactly those of the reference arithmetic (oracle order); the
+// speed comes from three accelerators that never decide a result unless a rigorous margin says the
+// exact arithmetic would agree, and otherwise fall back to it:
 //
-// Per view: (1) conservative frustum pre-cull, 3 FMAs per plane against n.p - off with an error
-// margin: "surely outside" lanes skip the view, "surely inside" lanes skip the exact plane test,
-// only lanes within the margin of a plane evaluate the reference's exact arithmetic
-// (f3d_inside_view) -- so the result is always the exact test's.  (2) exact canonical projection,
-// IEEE divisions, floor.  (3) bounds test, 1-byte mask gather (L2 / Infinity-Cache resident
-// masks).  (4) vote.
+//  (A) tile pre-cull, lanes-over-views.  Each wave reduces the bounding box of its 64 points, then
+//      lane j tests the box against the 5 planes of view 64g+j (float32 planes staged in LDS):
+//      box entirely behind a plane -> the whole wave skips that view; box entirely inside all planes
+//      -> no per-point cull for that view.  With a cell-sorted cloud ~55 % of (wave, view) pairs are
+//      skipped by a scalar bit-scan and ~30 % need no per-lane plane test.
+//  (B) per-point pre-cull in float32 for the remaining "mixed" views; lanes within the rounding
+//      margin of a plane evaluate the reference's exact float64 plane test (f3d_inside_view).
+//  (C) fast projection: h = M (p - t) with M = K Rot(qinv) (3 FMAs per row), one reciprocal; the
+//      pixel floor(u), floor(v) is accepted only if u and v are farther from an integer than a bound
+//      on |fast - canonical| (both are within ~50 eps * mnorm * |p-t|_1 / |h2| of the real value;
+//      the bound uses 2^-43, a >10x margin); otherwise the canonical sequence (un-normalised
+//      quaternion sandwich, K @ c, IEEE divisions -- camera_utils.py:21-25) is evaluated.
 //
-// Votes.  MODE_HIST8/16: a per-thread histogram in LDS laid out [label/4 (or /2)][thread] so that a
-// wave's accesses fall on 64 different dwords of consecutive banks (conflict-free); the vote is
-// one returning ds_add on the packed dword, and the running argmax (count desc, label asc -- the
-// first-maximum rule of np.argmax) is updated from the returned count, so no final scan is
-// needed without a filter.  MODE_FILTER8: with <= 8 filter classes only their counters and the
-// total matter: 8 register counters, no LDS.
+// The view record is read through scalar loads (wave-uniform) -> SGPR operands; the 1-byte mask
+// gather is software-pipelined (voted one view later); votes go to a per-thread LDS histogram laid
+// out [label/4][thread] (one dword per lane on 64 consecutive banks, conflict-free) with a running
+// argmax (count desc, label asc = first-maximum rule of np.argmax), or to 8 register counters when
+// filter_classes has <= 8 entries.
 // ------------------------------------------------------------------------------------------
 enum { MODE_HIST8 = 0, MODE_HIST16 = 1, MODE_FILTER8 = 2 };
 
@@ -100,60 +108,112 @@ template <> struct hist_traits<MODE_HIST8> { static constexpr int per_word = 4, 
 template <> struct hist_traits<MODE_HIST16> { static constexpr int per_word = 2, shift = 1, bits = 16; static constexpr uint32_t mask = 0xFFFFu; };
 template <> struct hist_traits<MODE_FILTER8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
 
+#define F3D_CULL_ROW 23                       // floats per view in the LDS cull table (22 used, odd stride = no bank conflicts)
+#define F3D_FAST_EPS 1.1368683772161603e-13   // 2^-43
+
+// per-point float32 cull against one view (SGPR-resident record): maybe = not surely outside, sure = surely inside
+__device__ __forceinline__ void cull_point32(const f3d_view& vw, float px, float py, float pz, float ps, bool small,
+                                             bool& maybe, bool& sure) {
+    const float marg = __builtin_fmaf(vw.cull_rel32, ps, vw.cull_abs32);
+    bool mb = true, sr = true;
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        const float a = __builtin_fmaf(vw.cull_n32[m][0], px,
+                        __builtin_fmaf(vw.cull_n32[m][1], py,
+                        __builtin_fmaf(vw.cull_n32[m][2], pz, -vw.cull_off32[m])));
+        mb = mb & (a > -marg);
+        sr = sr & (a > marg);
+    }
+    maybe = mb | !small;                      // huge / non-finite coordinates: only the exact test may decide
+    sure = sr & small;
+}
+
+// fast projection (C).  Returns true when (fu, fv) are proven equal to the canonical floors.
+__device__ __forceinline__ bool project_fast(const f3d_view& vw, f3d_p3 p, double& fu, double& fv) {
+    const double d0 = p.x - vw.t[0], d1 = p.y - vw.t[1], d2 = p.z - vw.t[2];
+    const double h0 = __builtin_fma(vw.M[0], d0, __builtin_fma(vw.M[1], d1, vw.M[2] * d2));
+    const double h1 = __builtin_fma(vw.M[3], d0, __builtin_fma(vw.M[4], d1, vw.M[5] * d2));
+    const double h2 = __builtin_fma(vw.M[6], d0, __builtin_fma(vw.M[7], d1, vw.M[8] * d2));
+    double r = __builtin_amdgcn_rcp(h2);
+    r = __builtin_fma(__builtin_fma(-h2, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-h2, r, 1.0), r, r);
+    const double uf = h0 * r, vf = h1 * r;
+    fu = floor(uf); fv = floor(vf);
+    const double scale = (F3D_FAST_EPS * ((fabs(d0) + fabs(d1)) + fabs(d2))) * fabs(r);
+    const double bu = __builtin_fma(__builtin_fma(fabs(uf), vw.mnorm[2], vw.mnorm[0]), scale, F3D_FAST_EPS * fabs(uf));
+    const double bv = __builtin_fma(__builtin_fma(fabs(vf), vw.mnorm[2], vw.mnorm[1]), scale, F3D_FAST_EPS * fabs(vf));
+    const double du = uf - fu, dv = vf - fv;
+    return (du > bu) & (du < 1.0 - bu) & (dv > bv) & (dv < 1.0 - bv);       // NaN / inf -> false
+}
+
+__device__ __forceinline__ void project_exact(const f3d_view& vw, f3d_p3 p, double& fu, double& fv) {
+    const f3d_p3 h = f3d_project_h(vw.K, vw.qinv, vw.t, p);
+    fu = floor(h.x / h.z); fv = floor(h.y / h.z);
+}
+
 template <typename T, int MODE, bool WRITE_VOTES>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
                                                      const uint8_t* __restrict__ masks, int H, int W,
                                                      int nclasses, f3d_filter_args flt, double threshold,
                                                      int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
-                                                     int* __restrict__ err) {
+                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz) {
     using HT = hist_traits<MODE>;
-    extern __shared__ uint32_t hist[];                     // [words_per_thread][F3D_BLOCK]
-    const int tid = threadIdx.x;
+    extern __shared__ uint32_t lds_u32[];
+    float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes of one view group
+    uint32_t* hist = lds_u32 + 64 * F3D_CULL_ROW;                         // [words_per_thread][F3D_BLOCK]
+    const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const int ncols = nclasses + 1;
     const int words = (ncols + HT::per_word - 1) >> HT::shift;
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
     const size_t plane = (size_t)H * (size_t)W;
+    const int ngroups = (nviews + 63) >> 6;
+
+    auto stage_group = [&](int g) {                                       // whole block; caller brackets with barriers
+        const int nv = min(64, nviews - 64 * g);
+        for (int k = tid; k < nv * 22; k += F3D_BLOCK) {
+            const int vi = k / 22, f = k - vi * 22;
+            ctab[vi * F3D_CULL_ROW + f] = reinterpret_cast<const float*>(&views[64 * g + vi].cull_n32[0][0])[f];
+        }
+    };
+    if (ngroups == 1) { stage_group(0); __syncthreads(); }
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t i = tile * F3D_BLOCK + tid;
         const bool live = i < n;
         f3d_p3 p = {0.0, 0.0, 0.0};
-        if (live) p = load_point(xyz, i);
+        const int64_t orig = (live && perm) ? (int64_t)perm[i] : i;               // caller-order index of this point
+        if (live) p = load_point(xyz, gather_xyz ? orig : i);
         const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
-        const bool finite = pscale < 1.0e300;              // false for inf / NaN coordinates
+        const float px32 = (float)p.x, py32 = (float)p.y, pz32 = (float)p.z, ps32 = (float)pscale;
+        const bool small = pscale < 1.0e30;                // float32 culls are meaningful (no overflow, no NaN)
+
+        // ---- (A) bounding box of this wave's live, well-behaved points
+        float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+        if (live & small) { lo0 = hi0 = px32; lo1 = hi1 = py32; lo2 = hi2 = pz32; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo0 = fminf(lo0, __shfl_xor(lo0, off, 64)); hi0 = fmaxf(hi0, __shfl_xor(hi0, off, 64));
+            lo1 = fminf(lo1, __shfl_xor(lo1, off, 64)); hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
+            lo2 = fminf(lo2, __shfl_xor(lo2, off, 64)); hi2 = fmaxf(hi2, __shfl_xor(hi2, off, 64));
+        }
+        const bool wave_odd = __any(live & !small);        // some lane needs the exact test whatever the box says
+        const bool wave_any = __any(live);
+        const float c0 = 0.5f * (lo0 + hi0), c1 = 0.5f * (lo1 + hi1), c2 = 0.5f * (lo2 + hi2);
+        const float e0 = 0.5f * (hi0 - lo0) * 1.000002f + 1e-30f, e1 = 0.5f * (hi1 - lo1) * 1.000002f + 1e-30f,
+                    e2 = 0.5f * (hi2 - lo2) * 1.000002f + 1e-30f;
+        const float ps_box = ((fabsf(c0) + fabsf(c1)) + fabsf(c2)) + ((e0 + e1) + e2);
 
         if (MODE != MODE_FILTER8) {
             for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;   // own column only: no barrier
         }
         int total = 0, best_c = 0, best_l = 0;
         int fc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool pend = false;                                  // software-pipelined gather: vote one view later
+        int pend_label = 0;
 
-        for (int v = 0; v < nviews; ++v) {
-            const f3d_view& vw = views[v];
-            // (1) conservative pre-cull
-            const double marg = __builtin_fma(vw.cull_rel, pscale, vw.cull_abs);
-            bool maybe = live, sure = finite;
-#pragma unroll
-            for (int m = 0; m < F3D_NPLANES; ++m) {
-                const double a = __builtin_fma(vw.plane_n[m][0], p.x,
-                                 __builtin_fma(vw.plane_n[m][1], p.y,
-                                 __builtin_fma(vw.plane_n[m][2], p.z, -vw.plane_off[m])));
-                maybe = maybe & (a > -marg);
-                sure = sure & (a > marg);
-            }
-            if (!maybe) continue;
-            if (!sure) {
-                if (!f3d_inside_view(vw, p)) continue;      // the reference's exact test decides
-            }
-            // (2) exact projection
-            const f3d_p3 h = f3d_project_h(vw.K, vw.qinv, vw.t, p);
-            const double fu = floor(h.x / h.z), fv = floor(h.y / h.z);
-            // (3) bounds + gather  (NaN compares false)
-            if (!(fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H)) continue;
-            const int label = masks[(size_t)v * plane + (size_t)(int)fv * (size_t)W + (size_t)(int)fu];
-            if (label > nclasses) { atomicOr(err, F3D_DEVERR_INDEX); continue; }   // IndexError in the reference
-            // (4) vote
+        auto vote = [&](int label) {
+            if (label > nclasses) { atomicOr(err, F3D_DEVERR_INDEX); return; }    // IndexError in the reference
             ++total;
             if (MODE == MODE_FILTER8) {
 #pragma unroll
@@ -164,7 +224,62 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 const int c = (int)((old >> sh) & HT::mask) + 1;
                 if (c > best_c || (c == best_c && label < best_l)) { best_c = c; best_l = label; }
             }
+        };
+
+        for (int g = 0; g < ngroups; ++g) {
+            if (ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
+            // lane j <-> view 64g + j: classify the wave's box against that view's planes
+            const int vj = 64 * g + lane;
+            bool box_out = false, box_in = true;
+            if (vj < nviews) {
+                const float* row = ctab + lane * F3D_CULL_ROW;
+                const float marg = 2.0f * __builtin_fmaf(row[20], ps_box, row[21]);
+#pragma unroll
+                for (int m = 0; m < F3D_NPLANES; ++m) {
+                    const float n0 = row[3 * m], n1 = row[3 * m + 1], n2 = row[3 * m + 2];
+                    const float base = __builtin_fmaf(n0, c0, __builtin_fmaf(n1, c1, __builtin_fmaf(n2, c2, -row[15 + m])));
+                    const float spread = __builtin_fmaf(fabsf(n0), e0, __builtin_fmaf(fabsf(n1), e1, fabsf(n2) * e2));
+                    box_out = box_out | (base + spread < -marg);
+                    box_in = box_in & (base - spread > marg);
+                }
+            }
+            unsigned long long valid_m = __ballot(vj < nviews);
+            unsigned long long out_m = __ballot(vj < nviews && box_out);
+            unsigned long long in_m = __ballot(vj < nviews && box_in && !box_out);
+            if (wave_odd) { out_m = 0ull; in_m = 0ull; }
+            if (!wave_any) out_m = valid_m;
+            unsigned long long todo = valid_m & ~out_m;
+            while (todo) {
+                const int bit = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int v = 64 * g + bit;
+                const f3d_view& vw = views[v];
+                bool inside = live;
+                if (!((in_m >> bit) & 1ull)) {              // mixed view: per-point float32 cull, exact test inside the margin
+                    bool maybe, sure;
+                    cull_point32(vw, px32, py32, pz32, ps32, small, maybe, sure);
+                    inside = live & maybe;
+                    if (__any(inside & !sure)) {
+                        if (inside & !sure) inside = f3d_inside_view(vw, p);
+                    }
+                }
+                bool hit = false;
+                size_t addr = 0;
+                if (inside) {
+                    double fu, fv;
+                    bool ok = project_fast(vw, p, fu, fv);
+                    if (!ok) project_exact(vw, p, fu, fv);  // canonical arithmetic decides
+                    if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) {
+                        hit = true;
+                        addr = (size_t)v * plane + (size_t)(int)fv * (size_t)W + (size_t)(int)fu;
+                    }
+                }
+                if (pend) vote(pend_label);                 // retire the previous view's vote, then issue this gather
+                pend = hit;
+                if (hit) pend_label = masks[addr];
+            }
         }
+        if (pend) vote(pend_label);
 
         // ---- VotingSegmentation.segment (voting.py:120-135) for this point
         int64_t cls;
@@ -203,13 +318,41 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 cls = r;
             }
         }
-        if (live) classes[i] = cls;
+        if (live) classes[orig] = cls;
         if (WRITE_VOTES && live) {
             for (int l = 0; l < ncols; ++l)
-                votes_out[(size_t)i * ncols + l] =
+                votes_out[(size_t)orig * ncols + l] =
                     (uint16_t)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
         }
     }
+}
+
+// Audit of accelerators (B) and (C) against the exact arithmetic, every (point, view) pair: see f3d_kernels.h
+template <typename T>
+__global__ __launch_bounds__(F3D_BLOCK) void k_fastpath_audit(const T* __restrict__ xyz, int64_t n,
+                                                               const f3d_view* __restrict__ views, int nviews,
+                                                               unsigned long long* __restrict__ stats) {
+    unsigned long long pairs = 0, fallback = 0, wrong = 0, cullwrong = 0;
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const f3d_p3 p = load_point(xyz, i);
+        const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
+        const bool small = pscale < 1.0e30;
+        for (int v = 0; v < nviews; ++v) {
+            const f3d_view& vw = views[v];
+            const bool in_exact = f3d_inside_view(vw, p);
+            bool maybe, sure;
+            cull_point32(vw, (float)p.x, (float)p.y, (float)p.z, (float)pscale, small, maybe, sure);
+            if ((sure && !in_exact) || (!maybe && in_exact)) ++cullwrong;
+            if (!in_exact) continue;
+            ++pairs;
+            double fu, fv, eu, ev;
+            const bool ok = project_fast(vw, p, fu, fv);
+            project_exact(vw, p, eu, ev);
+            if (!ok) ++fallback;
+            else if (!(fu == eu && fv == ev)) ++wrong;
+        }
+    }
+    atomicAdd(&stats[0], pairs); atomicAdd(&stats[1], fallback); atomicAdd(&stats[2], wrong); atomicAdd(&stats[3], cullwrong);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,9 +635,12 @@ hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, co
 
 size_t f3d_fuse_lds_bytes(int mode, int nclasses) {
     const int ncols = nclasses + 1;
-    if (mode == MODE_FILTER8) return 0;
-    const int per_word = (mode == MODE_HIST8) ? 4 : 2;
-    return (size_t)((ncols + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);
+    size_t hist = 0;
+    if (mode != MODE_FILTER8) {
+        const int per_word = (mode == MODE_HIST8) ? 4 : 2;
+        hist = (size_t)((ncols + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);
+    }
+    return 64 * F3D_CULL_ROW * sizeof(float) + hist;
 }
 
 int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
@@ -504,21 +650,20 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
 
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, int grid_blocks, hipStream_t s) {
+                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);
     const size_t lds = f3d_fuse_lds_bytes(mode, nclasses);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
-    int grid = grid_blocks > 0 ? grid_blocks : (int)(ntiles < F3D_GRID_CAP ? ntiles : F3D_GRID_CAP);
-    if (grid > ntiles) grid = (int)ntiles;
+    int grid = (int)(ntiles < F3D_GRID_CAP ? ntiles : F3D_GRID_CAP);
     const dim3 g(grid), b(F3D_BLOCK);
 #define F3D_FUSE(T, M, V)                                                                                      \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_fuse<T, M, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, masks, h, w,  \
-                           nclasses, flt, threshold, classes, votes, err);                                     \
+                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0);           \
     } while (0)
 #define F3D_FUSE_T(T)                                                                                          \
     do {                                                                                                       \
@@ -529,6 +674,16 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     if (dtype == F3D_F64) F3D_FUSE_T(double); else F3D_FUSE_T(float);
 #undef F3D_FUSE_T
 #undef F3D_FUSE
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_fastpath_audit(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                                     unsigned long long* stats_dev, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(stats_dev, 0, 4 * sizeof(unsigned long long), s);
+    if (e != hipSuccess || n <= 0) return e;
+    const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+    if (dtype == F3D_F64) hipLaunchKernelGGL(k_fastpath_audit<double>, g, b, 0, s, (const double*)xyz, n, views_dev, nviews, stats_dev);
+    else hipLaunchKernelGGL(k_fastpath_audit<float>, g, b, 0, s, (const float*)xyz, n, views_dev, nviews, stats_dev);
     return hipGetLastError();
 }
 

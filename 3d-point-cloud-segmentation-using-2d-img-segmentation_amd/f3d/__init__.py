@@ -16,11 +16,12 @@ from pathlib import Path
 import numpy as np
 
 __all__ = ['F3DError', 'F3DUnavailable', 'Context', 'default_context', 'library', 'library_path',
-           'views_build', 'frustum_data', 'quat_inverse', 'VIEW_DOUBLES', 'F64', 'F32']
+           'views_build', 'frustum_data', 'quat_inverse', 'VIEW_DOUBLES', 'F64', 'F32', 'FUSE_SORT']
 
 F64, F32 = 0, 1
+FUSE_SORT = 2
 OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_ZERO_QUAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5
-VIEW_DOUBLES = 53            # sizeof(f3d_view) / 8
+VIEW_DOUBLES = 80            # sizeof(f3d_view) / 8
 OBB_DOUBLES = 15             # sizeof(f3d_obb) / 8
 MAX_OBB = 4096
 
@@ -77,7 +78,9 @@ def library():
         'f3d_project_view_f64': (i32, [vp, vp, i64, vp, vp, vp]),
         'f3d_project_view_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),
         'f3d_project_vote_argmax': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp]),
-        'f3d_project_vote_argmax_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp, vp]),
+        'f3d_project_vote_argmax_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp, C.c_uint, vp, vp]),
+        'f3d_debug_fastpath_audit': (i32, [vp, vp, i32, i64, vp, i32, vp]),
+        'f3d_cloud_sort_cells_dev': (i32, [vp, vp, i32, i64, vp, vp, vp]),
         'f3d_take_device_error': (i32, [vp, vp]),
         'f3d_vote_uv2pt': (i32, [vp, vp, vp, i64, vp, i64, i32]),
         'f3d_vote_uv2pt_dev': (i32, [vp, vp, vp, i64, vp, i64, i32, vp]),
@@ -149,7 +152,7 @@ def frustum_data(K, w, h, wxyzs, translations):
 
 
 def views_build(K, w, h, wxyzs, translations, max_depth):
-    """Packed per-view records (float64 [V, 53]) consumed by the fused kernels."""
+    """Packed per-view records (640 bytes each, viewed as float64 [V, 80]) consumed by the fused kernels."""
     K = _f64(K, (3, 3))
     q = _f64(np.atleast_2d(wxyzs))
     t = _f64(np.atleast_2d(translations))
@@ -164,11 +167,11 @@ def views_build(K, w, h, wxyzs, translations, max_depth):
 
 
 def view_fields(views):
-    """Named sub-arrays of a [V,53] view table (for tests and debugging)."""
+    """Named sub-arrays of a [V,80] view table (for tests and debugging)."""
     v = np.asarray(views)
     return {'K': v[:, 0:9].reshape(-1, 3, 3), 'qinv': v[:, 9:13], 't': v[:, 13:16],
             'plane_pt': v[:, 16:31].reshape(-1, 5, 3), 'plane_n': v[:, 31:46].reshape(-1, 5, 3),
-            'plane_off': v[:, 46:51], 'cull_rel': v[:, 51], 'cull_abs': v[:, 52]}
+            'M': v[:, 46:55].reshape(-1, 3, 3), 'mnorm': v[:, 55:58]}
 
 
 def _xyz(points):
@@ -263,7 +266,7 @@ class Context:
         views = _f64(views)
         masks = np.ascontiguousarray(masks, dtype=np.uint8)
         if masks.ndim != 3 or views.ndim != 2 or views.shape[1] != VIEW_DOUBLES or len(views) != len(masks):
-            raise ValueError('views must be [V,53] and masks uint8 [V,H,W]')
+            raise ValueError(f'views must be [V,{VIEW_DOUBLES}] and masks uint8 [V,H,W]')
         V, H, W = masks.shape
         f, nf = _filter(filter_classes)
         cls = np.empty(len(p), np.int64)
@@ -330,11 +333,22 @@ class Context:
 
     # ---------------------------------------------------------------- device-pointer calls
     def project_vote_argmax_dev(self, xyz_ptr, dtype, n, views_ptr, nviews, masks_ptr, h, w, nclasses, threshold,
-                                filter_classes, classes_ptr, votes_ptr=None, stream=None):
+                                filter_classes, classes_ptr, votes_ptr=None, stream=None, flags=0, perm_ptr=None):
         f, nf = _filter(filter_classes)
         self._check(self._lib.f3d_project_vote_argmax_dev(self._h, xyz_ptr, dtype, n, views_ptr, nviews, masks_ptr, h, w,
                                                           int(nclasses), _ptr(f), nf, float(threshold), classes_ptr,
-                                                          votes_ptr, stream))
+                                                          votes_ptr, int(flags), perm_ptr, stream))
+
+    def cloud_sort_cells_dev(self, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream=None):
+        self._check(self._lib.f3d_cloud_sort_cells_dev(self._h, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream))
+
+    def fastpath_audit(self, points, views):
+        """(pairs inside, pairs sent to the exact fallback, accepted-but-different pairs, contradicted culls)."""
+        p, dt = _xyz(points)
+        v = _f64(views)
+        stats = np.zeros(4, np.uint64)
+        self._check(self._lib.f3d_debug_fastpath_audit(self._h, _ptr(p), dt, len(p), _ptr(v), len(v), _ptr(stats)))
+        return tuple(int(x) for x in stats)
 
     def take_device_error(self, stream=None):
         self._check(self._lib.f3d_take_device_error(self._h, stream))

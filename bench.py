@@ -46,7 +46,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the streaming-kernel measurements')
     ap.add_argument('--cpu-sample', type=int, default=100_000)
-    ap.add_argument('--sorted', action='store_true', help='experiment: store the cloud in spatially sorted (grid-cell) order')
+    ap.add_argument('--sorted', action='store_true', help='experiment: hand the cloud over already in grid-cell order (host sort)')
+    ap.add_argument('--no-sort', action='store_true', help='do not cell-sort the cloud inside the step')
+    ap.add_argument('--prepared', action='store_true', help='cell-sort once outside the timed loop and keep the sorted cloud resident')
     return ap.parse_args()
 
 
@@ -131,9 +133,24 @@ def main():
     stream = torch.cuda.Stream(dev)          # a real (non-null) HIP stream: kernels, RCCL and the timing events all use it
     torch.cuda.set_stream(stream)
 
+    flags = 0
+    perm_ptr = None
+    layout = 'caller order, cell-sorted inside every step (F3D_FUSE_SORT)'
+    if args.prepared:
+        xyz_sorted = torch.empty_like(xyz)
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        ctx.cloud_sort_cells_dev(xyz.data_ptr(), dtype, n, xyz_sorted.data_ptr(), perm.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        xyz, perm_ptr = xyz_sorted, perm.data_ptr()
+        layout = 'prepared: cell-sorted once outside the timed region, sorted copy + permutation resident'
+    elif args.no_sort or args.sorted:
+        layout = 'caller order, no sort' + (' (cloud handed over pre-sorted by the host)' if args.sorted else '')
+    else:
+        flags |= f3d.FUSE_SORT
+
     def fuse():
         ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, masks_full.data_ptr(), S, S,
-                                    133, 0.5, flt, classes.data_ptr(), None, stream.cuda_stream)
+                                    133, 0.5, flt, classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
 
     def step():
         if world > 1:
@@ -182,7 +199,7 @@ def main():
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
                    config=dict(workload=f'C3: {n} points/GPU x {V} ring views, {S}x{S} {args.masks} uint8 masks, '
                                         f'nclasses=133, threshold=0.5, filter_classes={flt}; fused project->sample->vote->segment',
-                               points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64',
+                               points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64', cloud_layout=layout,
                                exchange='none' if world == 1 else f'RCCL all_gather of {V // world} masks/rank each step'),
                    roofline=roofline)
 

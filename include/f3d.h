@@ -53,18 +53,31 @@ typedef enum f3d_dtype {
     F3D_F32 = 1                   /* xyz stored as float32 [N,3]; widened to f64 in registers     */
 } f3d_dtype;
 
-/* One camera view, in the form the kernels consume (all float64, 8-byte aligned, 53 doubles).
- * Built on the host by f3d_views_build(); the fused kernel reads it through scalar loads /
- * stages it in LDS. */
+/* One camera view, in the form the kernels consume (8-byte aligned, 640 bytes = 80 doubles).
+ * Built on the host by f3d_views_build(); the fused kernel reads it through scalar loads and
+ * stages the float32 cull planes in LDS.
+ *   exact data (the reference's arithmetic uses exactly these):  K, qinv, t, plane_pt, plane_n
+ *   accelerators (never decide a result on their own, see DESIGN.md "fast paths"):
+ *     M, mnorm      : M = K * Rot(qinv) rounded once from extended precision; mnorm[k] bounds the
+ *                     row-k operand magnitudes.  The fast projection h = M (p - t) is accepted only
+ *                     when its floor provably equals the canonical path's; otherwise the canonical
+ *                     arithmetic (camera_utils.py:21-25 order) is evaluated.
+ *     cull_*32      : float32 copy of the planes, a = n32 . p32 - off32; a point (or a whole tile's
+ *                     bounding box) is accepted/rejected without the exact plane test only when |a|
+ *                     exceeds rel32 * (|x|+|y|+|z|) + abs32. */
 typedef struct f3d_view {
     double K[9];                  /* intrinsics, row-major (camera_utils.py:23)                   */
     double qinv[4];               /* conj(q)/|q|^2 (w,x,y,z)  (camera_utils.py:22)                */
     double t[3];                  /* camera translation       (camera_utils.py:21)                */
     double plane_pt[F3D_NPLANES][3];   /* fusion.py:254-257                                       */
     double plane_n[F3D_NPLANES][3];    /* inward normals, fusion.py:256-258                       */
-    double plane_off[F3D_NPLANES];     /* n . plane_pt, only used by the conservative pre-cull    */
-    double cull_rel;              /* pre-cull margin = cull_rel * (|x|+|y|+|z|) + cull_abs: a point  */
-    double cull_abs;              /* closer than that to a plane is decided by the exact plane test */
+    double M[9];                  /* K * Rot(qinv), row-major                                     */
+    double mnorm[3];              /* ||K row k||_1 * |qinv|^2, rounded up                          */
+    float  cull_n32[F3D_NPLANES][3];
+    float  cull_off32[F3D_NPLANES];
+    float  cull_rel32;
+    float  cull_abs32;
+    double reserved[11];
 } f3d_view;
 
 /* An oriented box as open3d's OrientedBoundingBox exposes it (center, R columns = axes, extent);
@@ -135,12 +148,31 @@ int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
                             const uint8_t* masks /*[V,H,W]*/, int h, int w,
                             int nclasses, const int32_t* filter, int nfilter, double threshold,
                             int64_t* classes, uint16_t* votes_u16);
+/* flags for the device variant (results never depend on them):
+ *   F3D_FUSE_SORT     the cloud is in arbitrary order: cell-sort it inside the call (into context
+ *                     scratch, ~4 HBM passes over xyz) so that a wavefront's 64 points are spatial
+ *                     neighbours and culled waves skip the projection; labels are written back in the
+ *                     caller's order.  `perm` must be NULL.
+ * perm (device, may be NULL): xyz is a cell-sorted copy produced by f3d_cloud_sort_cells_dev and
+ * perm[i] is the caller-order index of sorted point i; classes/votes are written at perm[i]. */
+#define F3D_FUSE_SORT    2u
 int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
                                 const f3d_view* views_dev /*device [V]*/, int nviews,
                                 const uint8_t* masks, int h, int w,
                                 int nclasses, const int32_t* filter /*host*/, int nfilter,
                                 double threshold, int64_t* classes, uint16_t* votes_u16,
-                                void* stream);
+                                unsigned flags, const int32_t* perm, void* stream);
+/* Test hook: evaluates, for every (point, view) pair, the accelerated decisions of the fused
+ * kernel next to the exact arithmetic.  stats[0] = pairs inside the frustum, stats[1] = pairs the
+ * fast projection hands to the exact fallback, stats[2] = accepted pairs whose pixel differs from
+ * the canonical path (must be 0), stats[3] = float32 cull decisions the exact plane test
+ * contradicts (must be 0).  Host pointers. */
+int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                             const f3d_view* views, int nviews, uint64_t stats[4]);
+/* Sort of the cloud by coarse grid cell: sorted_xyz (same dtype/size as xyz) and perm
+ * (int32 [n], caller-order index of sorted point i), both device buffers owned by the caller. */
+int f3d_cloud_sort_cells_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
+                             void* sorted_xyz, int32_t* perm, void* stream);
 /* Returns and clears the sticky error recorded by _dev kernels of this context
  * (F3D_OK or F3D_ERR_INDEX).  Synchronises the context's error word only. */
 int f3d_take_device_error(f3d_ctx* ctx, void* stream);

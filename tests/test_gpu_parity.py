@@ -172,3 +172,120 @@ def test_vote_and_segment_larger_random(ctx):
     assert np.array_equal(votes, want)
     for thr, flt in [(0.5, None), (0.5, [86, 114, 115]), (0.1, list(range(100, 134)))]:
         assert np.array_equal(ctx.segment_votes(votes, 133, thr, flt), O.segment(want, 133, thr, flt))
+
+
+def _dev_fuse(ctx, pts, views, masks, flt, thr, flags, presort=False, f32=False):
+    import torch
+    dev = torch.device('cuda', 0)
+    x = torch.from_numpy(pts.astype(np.float32) if f32 else pts).to(dev)
+    vd = torch.from_numpy(views).to(dev)
+    md = torch.from_numpy(masks).to(dev)
+    n = len(pts)
+    cls = torch.full((n,), -7, dtype=torch.int64, device=dev)
+    s = torch.cuda.Stream(dev)
+    dt = f3d.F32 if f32 else f3d.F64
+    with torch.cuda.stream(s):
+        perm_ptr = None
+        if presort:
+            xs = torch.empty_like(x)
+            perm = torch.empty(n, dtype=torch.int32, device=dev)
+            ctx.cloud_sort_cells_dev(x.data_ptr(), dt, n, xs.data_ptr(), perm.data_ptr(), s.cuda_stream)
+            s.synchronize()
+            assert np.array_equal(np.sort(perm.cpu().numpy()), np.arange(n))          # a permutation
+            assert np.array_equal(xs.cpu().numpy(), x.cpu().numpy()[perm.cpu().numpy()])
+            x, perm_ptr = xs, perm.data_ptr()
+        V, H, W = masks.shape
+        ctx.project_vote_argmax_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, md.data_ptr(), H, W, 133, thr, flt,
+                                    cls.data_ptr(), None, s.cuda_stream, flags=flags, perm_ptr=perm_ptr)
+        ctx.take_device_error(s.cuda_stream)
+        s.synchronize()
+    return cls.cpu().numpy()
+
+
+def test_device_api_sort_flags_and_prepared_layout(ctx):
+    sc = synth.scene('C1', n=100_000, mask_kind='iid')
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
+                                 133, 0.5, None)
+    for flags in (0, f3d.FUSE_SORT):
+        assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, flags), want), flags
+    assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, 0, presort=True), want)
+    assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, f3d.FUSE_SORT, f32=True), want)
+    # host entry point sorts clouds of this size by itself
+    assert np.array_equal(ctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, 0.5, None), want)
+    want_f = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
+                                   133, 0.5, [86, 114, 115])
+    got, votes = ctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, 0.5, [86, 114, 115], return_votes=True)
+    assert np.array_equal(got, want_f)
+    assert np.array_equal(votes.astype(np.float64),
+                          O.forward_votes(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth']))
+
+
+def test_general_K_matches(ctx):
+    sc = synth.scene('C1', n=20000)
+    K = np.array([[410.5, 1.75, 250.25], [0.125, 395.0, 260.5], [0., 0., 1.]])
+    views = f3d.views_build(K, sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    want = O.project_vote_argmax(sc['points'], K, sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'])
+    assert np.array_equal(ctx.project_vote_argmax(sc['points'], views, sc['masks']), want)
+
+
+def test_sort_handles_nonfinite_and_degenerate_clouds(ctx):
+    sc = synth.scene('C1', n=70000)
+    pts = sc['points'].copy()
+    pts[::1000] = np.nan
+    pts[1::1000, 0] = np.inf
+    pts[5] = 1e308
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    with np.errstate(all='ignore'):
+        want = O.project_vote_argmax(pts, sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'])
+    assert np.array_equal(ctx.project_vote_argmax(pts, views, sc['masks']), want)
+    same = np.repeat(sc['points'][:1], 70000, axis=0)                          # zero-extent bounding box
+    want = O.project_vote_argmax(same, sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'])
+    assert np.array_equal(ctx.project_vote_argmax(same, views, sc['masks']), want)
+
+
+def _near_pixel_boundary_points(K, q, t, rng, count, w, h):
+    """World points whose exact projection lies within a few ulp of an integer pixel coordinate."""
+    R = np.stack([O.rotate(q, np.eye(3)[k:k + 1])[0] for k in range(3)], axis=1)      # camera->world of unit axes
+    u = rng.integers(1, w - 1, count).astype(np.float64)
+    v = rng.uniform(1, h - 1, count)
+    z = rng.uniform(0.3, 9.0, count)
+    cam = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], axis=1)
+    return cam @ R.T / np.dot(q, q) + t
+
+
+def test_fast_projection_and_f32_cull_never_disagree_with_exact(ctx):
+    rng = np.random.default_rng(77)
+    sc = synth.scene('C3', n=1)
+    q, t, K = sc['wxyzs'], sc['translations'], sc['K']
+    q = q.copy(); q[3] *= 1.7; q[5] *= -0.4                                    # un-normalised poses too
+    views = f3d.views_build(K, sc['w'], sc['h'], q, t, sc['max_depth'])
+    clouds = [synth.cloud(400_000),                                            # f32-representable
+              rng.uniform([-5, -5, 0], [5, 5, 3], (200_000, 3)),               # full f64 mantissas
+              t[rng.integers(0, len(t), 50_000)] + rng.normal(size=(50_000, 3)) * 1e-3,   # hugging the eyes (z -> 0)
+              np.vstack([_near_pixel_boundary_points(K, q[j], t[j], rng, 4000, sc['w'], sc['h']) for j in range(0, 64, 4)])]
+    fallbacks = 0
+    for pts in clouds:
+        pairs, fb, wrong, cullwrong = ctx.fastpath_audit(pts, views)
+        assert pairs > 0 and wrong == 0 and cullwrong == 0, (pairs, fb, wrong, cullwrong)
+        fallbacks += fb
+    assert fallbacks > 0                                                       # the fallback branch really runs
+    # ... and the fused kernel agrees with the oracle on the adversarial sets
+    pts = np.vstack([c[:20000] for c in clouds])
+    with np.errstate(all='ignore'):
+        want = O.project_vote_argmax(pts, K, q, t, sc['masks'], sc['max_depth'])
+    assert np.array_equal(ctx.project_vote_argmax(pts, views, sc['masks']), want)
+
+
+def test_views_record_fast_operator_matches_canonical_rotation():
+    sc = synth.scene('C2', n=1)
+    q = sc['wxyzs'].copy(); q[2] *= 3.0
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], q, sc['translations'], 10.0)
+    F = f3d.view_fields(views)
+    d = np.random.default_rng(1).normal(size=(100, 3))
+    for j in range(len(q)):
+        c = O.rotate(F['qinv'][j], d)
+        want = (sc['K'] @ c.T).T
+        got = d @ F['M'][j].T
+        assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+        assert (F['mnorm'][j] >= np.abs(sc['K']).sum(1) * np.dot(F['qinv'][j], F['qinv'][j])).all()
