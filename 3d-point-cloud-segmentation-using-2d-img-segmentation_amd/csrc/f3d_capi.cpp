@@ -416,7 +416,7 @@ int f3d_inside_polyhedra_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const d
 int f3d_cloud_sort_cells_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, void* sorted_xyz, int32_t* perm,
                              void* stream) {
     int rc = enter(ctx); if (rc) return rc;
-    if (n < 0 || n > 0x7fffffffLL || (n > 0 && (!xyz || !sorted_xyz || !perm)))
+    if (n < 0 || n > 0x7fffffffLL || (n > 0 && (!xyz || !perm)))
         return fail(ctx, F3D_ERR_INVALID, "cloud_sort_cells: bad arguments (n < 2^31)");
     if (n == 0) return F3D_OK;
     void* scratch;
@@ -438,7 +438,7 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
     hipStream_t s = pick(ctx, stream);
     f3d_filter_args fa;
     if ((rc = make_filter(ctx, filter, nfilter, nclasses + 1, true, s, &fa))) return rc;
-    bool gather = false;
+    bool gather = (flags & F3D_FUSE_GATHER) && perm;
     if ((flags & F3D_FUSE_SORT) && n > 512 && n <= 0x7fffffffLL) {
         void *sperm, *scratch;                                                                  // grow on first use only
         if ((rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &sperm))) return rc;

@@ -128,8 +128,10 @@ __device__ __forceinline__ void cull_point32(const f3d_view& vw, float px, float
     sure = sr & small;
 }
 
-// fast projection (C).  Returns true when (fu, fv) are proven equal to the canonical floors.
-__device__ __forceinline__ bool project_fast(const f3d_view& vw, f3d_p3 p, double& fu, double& fv) {
+// fast projection (C).  Returns true when (iu, iv) are proven equal to the canonical floor(u), floor(v) AND lie inside
+// the W x H image; `unsure` is set when the canonical arithmetic has to decide.  umax >= max(W, H): for |u| <= umax
+// the bound is rigorous; beyond it both paths are out of the image anyway.
+__device__ __forceinline__ bool project_fast(const f3d_view& vw, f3d_p3 p, int W, int H, double umax, int& iu, int& iv, bool& unsure) {
     const double d0 = p.x - vw.t[0], d1 = p.y - vw.t[1], d2 = p.z - vw.t[2];
     const double h0 = __builtin_fma(vw.M[0], d0, __builtin_fma(vw.M[1], d1, vw.M[2] * d2));
     const double h1 = __builtin_fma(vw.M[3], d0, __builtin_fma(vw.M[4], d1, vw.M[5] * d2));
@@ -138,12 +140,31 @@ __device__ __forceinline__ bool project_fast(const f3d_view& vw, f3d_p3 p, doubl
     r = __builtin_fma(__builtin_fma(-h2, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-h2, r, 1.0), r, r);
     const double uf = h0 * r, vf = h1 * r;
-    fu = floor(uf); fv = floor(vf);
-    const double scale = (F3D_FAST_EPS * ((fabs(d0) + fabs(d1)) + fabs(d2))) * fabs(r);
-    const double bu = __builtin_fma(__builtin_fma(fabs(uf), vw.mnorm[2], vw.mnorm[0]), scale, F3D_FAST_EPS * fabs(uf));
-    const double bv = __builtin_fma(__builtin_fma(fabs(vf), vw.mnorm[2], vw.mnorm[1]), scale, F3D_FAST_EPS * fabs(vf));
-    const double du = uf - fu, dv = vf - fv;
-    return (du > bu) & (du < 1.0 - bu) & (dv > bv) & (dv < 1.0 - bv);       // NaN / inf -> false
+    const double fu = floor(uf), fv = floor(vf);
+    // |fast - canonical| <= 2^-43 * (|d|_1 |r| (mnorm_k + |u| mnorm_2) + |u|), evaluated with |u| <= umax (wave-uniform part in SGPRs)
+    const double c1 = __builtin_fma(umax, vw.mnorm[2], fmax(vw.mnorm[0], vw.mnorm[1]));
+    const double b = __builtin_fma((F3D_FAST_EPS * ((fabs(d0) + fabs(d1)) + fabs(d2))) * fabs(r), c1, F3D_FAST_EPS * umax);
+    // frac in (b, 1-b)  <=>  |frac - 0.5| < 0.5 - b      (NaN / inf -> false)
+    const bool safe = (fabs((uf - fu) - 0.5) < 0.5 - b) && (fabs((vf - fv) - 0.5) < 0.5 - b);
+    unsure = !safe;
+    iu = (int)fu; iv = (int)fv;                              // saturating conversions; only used when safe
+    return safe & ((unsigned)iu < (unsigned)W) & ((unsigned)iv < (unsigned)H);
+}
+
+// canonical fallbacks (out-of-line versions raised the kernel's VGPR allocation through the call ABI, so they are inlined)
+__device__ __forceinline__ bool project_exact_cold(const f3d_view* vw, double px, double py, double pz, int W, int H,
+                                                              int* iu, int* iv) {
+    f3d_p3 p; p.x = px; p.y = py; p.z = pz;
+    const f3d_p3 h = f3d_project_h(vw->K, vw->qinv, vw->t, p);
+    const double fu = floor(h.x / h.z), fv = floor(h.y / h.z);
+    const bool in = (fu >= 0.0) & (fu < (double)W) & (fv >= 0.0) & (fv < (double)H);      // NaN compares false
+    *iu = in ? (int)fu : 0; *iv = in ? (int)fv : 0;
+    return in;
+}
+
+__device__ __forceinline__ bool inside_view_cold(const f3d_view* vw, double px, double py, double pz) {
+    f3d_p3 p; p.x = px; p.y = py; p.z = pz;
+    return f3d_inside_view(*vw, p);
 }
 
 __device__ __forceinline__ void project_exact(const f3d_view& vw, f3d_p3 p, double& fu, double& fv) {
@@ -168,6 +189,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
     const size_t plane = (size_t)H * (size_t)W;
     const int ngroups = (nviews + 63) >> 6;
+    const double umax = (double)(W > H ? W : H);
 
     auto stage_group = [&](int g) {                                       // whole block; caller brackets with barriers
         const int nv = min(64, nviews - 64 * g);
@@ -260,23 +282,21 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                     cull_point32(vw, px32, py32, pz32, ps32, small, maybe, sure);
                     inside = live & maybe;
                     if (__any(inside & !sure)) {
-                        if (inside & !sure) inside = f3d_inside_view(vw, p);
+                        if (inside & !sure) inside = inside_view_cold(&vw, p.x, p.y, p.z);
                     }
                 }
                 bool hit = false;
-                size_t addr = 0;
+                int iu = 0, iv = 0;
                 if (inside) {
-                    double fu, fv;
-                    bool ok = project_fast(vw, p, fu, fv);
-                    if (!ok) project_exact(vw, p, fu, fv);  // canonical arithmetic decides
-                    if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) {
-                        hit = true;
-                        addr = (size_t)v * plane + (size_t)(int)fv * (size_t)W + (size_t)(int)fu;
+                    bool unsure;
+                    hit = project_fast(vw, p, W, H, umax, iu, iv, unsure);
+                    if (__any(unsure)) {                    // canonical arithmetic decides
+                        if (unsure) hit = project_exact_cold(&vw, p.x, p.y, p.z, W, H, &iu, &iv);
                     }
                 }
                 if (pend) vote(pend_label);                 // retire the previous view's vote, then issue this gather
                 pend = hit;
-                if (hit) pend_label = masks[addr];
+                if (hit) pend_label = (masks + (size_t)v * plane)[(unsigned)(iv * W + iu)];
             }
         }
         if (pend) vote(pend_label);
@@ -345,11 +365,16 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fastpath_audit(const T* __restric
             if ((sure && !in_exact) || (!maybe && in_exact)) ++cullwrong;
             if (!in_exact) continue;
             ++pairs;
-            double fu, fv, eu, ev;
-            const bool ok = project_fast(vw, p, fu, fv);
+            // audit with a 1024 x 1024 image, and with a tiny one so that the out-of-image rule is exercised as well
+            double eu, ev;
             project_exact(vw, p, eu, ev);
-            if (!ok) ++fallback;
-            else if (!(fu == eu && fv == ev)) ++wrong;
+            for (int dim = 1024; dim >= 16; dim >>= 6) {
+                int iu, iv; bool unsure;
+                const bool hit = project_fast(vw, p, dim, dim, (double)dim, iu, iv, unsure);
+                const bool ehit = (eu >= 0.0) & (eu < (double)dim) & (ev >= 0.0) & (ev < (double)dim);
+                if (unsure) { if (dim == 1024) ++fallback; }
+                else if (hit != ehit || (hit && !((double)iu == eu && (double)iv == ev))) ++wrong;
+            }
         }
     }
     atomicAdd(&stats[0], pairs); atomicAdd(&stats[1], fallback); atomicAdd(&stats[2], wrong); atomicAdd(&stats[3], cullwrong);

@@ -153,9 +153,13 @@ int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
  *                     scratch, ~4 HBM passes over xyz) so that a wavefront's 64 points are spatial
  *                     neighbours and culled waves skip the projection; labels are written back in the
  *                     caller's order.  `perm` must be NULL.
- * perm (device, may be NULL): xyz is a cell-sorted copy produced by f3d_cloud_sort_cells_dev and
- * perm[i] is the caller-order index of sorted point i; classes/votes are written at perm[i]. */
+ *   F3D_FUSE_GATHER   with `perm`: xyz is still the caller-order cloud and the kernel reads point
+ *                     perm[i] (what F3D_FUSE_SORT does internally; lets a caller time / reuse the sort).
+ * perm (device, may be NULL): perm[i] is the caller-order index of the i-th point in cell order
+ * (from f3d_cloud_sort_cells_dev); without F3D_FUSE_GATHER xyz must be the sorted copy.
+ * classes/votes are always written at caller-order indices. */
 #define F3D_FUSE_SORT    2u
+#define F3D_FUSE_GATHER  4u
 int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
                                 const f3d_view* views_dev /*device [V]*/, int nviews,
                                 const uint8_t* masks, int h, int w,
@@ -169,8 +173,8 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
  * contradicts (must be 0).  Host pointers. */
 int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
                              const f3d_view* views, int nviews, uint64_t stats[4]);
-/* Sort of the cloud by coarse grid cell: sorted_xyz (same dtype/size as xyz) and perm
- * (int32 [n], caller-order index of sorted point i), both device buffers owned by the caller. */
+/* Sort of the cloud by coarse grid cell: perm (int32 [n], caller-order index of sorted point i)
+ * and, unless NULL, sorted_xyz (same dtype/size as xyz); device buffers owned by the caller. */
 int f3d_cloud_sort_cells_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
                              void* sorted_xyz, int32_t* perm, void* stream);
 /* Returns and clears the sticky error recorded by _dev kernels of this context

@@ -1,0 +1,82 @@
+"""Host-side logic of the drop-in modules (no GPU needed)."""
+import json
+
+import numpy as np
+import pytest
+
+from Fusion3DSeg.segUtils.cv import split_into_instances
+from Fusion3DSeg.segUtils.voting import VotingSegmentation, resize_nearest
+from Fusion3DSeg.merge_intersecting_bb import obb_from_points, obb_corners
+import get3DSeg
+from oracle import np_ref as O
+
+
+def test_split_into_instances_matches_reference_golden(golden):
+    g = golden('split_instances')
+    offs, flat = g['adj_offsets'], g['adj_flat']
+    adj = [flat[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    for i in range(int(g['ncases'])):
+        ic = g[f'case{i}_instance_classes'].tolist() if g[f'case{i}_has_instance_classes'] else None
+        insts, ids, info, newcls = split_into_instances(g['classes'], adj, 133, ic, int(g[f'case{i}_minimum_points']))
+        assert len(insts) == int(g[f'case{i}_ninst'])
+        assert np.array_equal(ids, g[f'case{i}_ids'])
+        assert np.array_equal(newcls, g[f'case{i}_classes'])
+        got = np.array([[d['id'], int(d['isthing']), d['category_id'], d['area']] for d in info], np.int64).reshape(-1, 4)
+        assert np.array_equal(got, g[f'case{i}_info'])
+
+
+def test_resize_nearest_index_rule():
+    m = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    assert np.array_equal(resize_nearest(m, 4, 3), m)
+    up = resize_nearest(m, 8, 6)
+    assert up.shape == (6, 8) and np.array_equal(up[::2, ::2], m)
+    down = resize_nearest(np.arange(64, dtype=np.uint8).reshape(8, 8), 4, 4)
+    assert np.array_equal(down, np.arange(64).reshape(8, 8)[::2, ::2])
+
+
+def test_voting_constructor_pairs_frames_by_stem_and_q2(tmp_path):
+    from PIL import Image
+    md, ud = tmp_path / 'masks', tmp_path / 'uv2pt'
+    md.mkdir(); ud.mkdir()
+    for stem in ('a', 'b', 'c'):
+        Image.fromarray(np.zeros((4, 4), np.uint8)).save(md / f'{stem}.png')
+    for stem in ('b', 'c', 'd'):
+        np.save(ud / f'{stem}.npy', np.full(16, -1, np.int32))
+    v = VotingSegmentation(10, (4, 4), md, ud, 133)
+    assert v.votes.shape == (10, 134) and v.votes.dtype == np.float64 and v.nframes == 2
+    assert sorted(p.stem for p in v.mask_files) == ['b', 'c'] == sorted(p.stem for p in v.uv2pt_files)
+    np.save(tmp_path / 'votes.npy', np.ones((10, 134)))
+    v2 = VotingSegmentation(10, (4, 4), md, ud, 133, votes_file=tmp_path / 'votes.npy')
+    assert v2.nclasses == 134                                       # quirk Q2
+
+
+def test_ply_round_trip(tmp_path):
+    pts = np.random.default_rng(0).normal(size=(50, 3))
+    get3DSeg.write_ply(tmp_path / 'a.ply', get3DSeg.PointCloud(pts, np.random.default_rng(1).random((50, 3)), pts))
+    assert np.array_equal(get3DSeg.read_ply_points(tmp_path / 'a.ply'), pts)
+
+
+def test_obb_fit_contains_its_points_and_matches_oracle_recipe():
+    rng = np.random.default_rng(2)
+    pts = rng.normal(size=(300, 3)) * [2.0, 0.5, 0.1] @ np.linalg.qr(rng.normal(size=(3, 3)))[0].T + [1, 2, 3]
+    c, R, e = obb_from_points(pts)
+    assert O.points_in_obb(pts, c, R, e * (1 + 1e-12)).all()
+    c2, R2, e2 = O.obb_from_points(pts)
+    assert np.allclose(c, c2) and np.allclose(e, e2) and np.allclose(np.abs(R), np.abs(R2))
+    assert obb_corners(c, R, e).shape == (8, 3)
+    assert e[0] >= e[1] >= e[2]
+
+
+def test_load_csv(tmp_path):
+    (tmp_path / 'classes.csv').write_text('Class_ID,Parent,Parent_ID,flag_infojson,flag_objremoval\n86,wall,1,1,0\n114,floor,2,1,0\n3,car,5,0,1\n')
+    cid, pname, pid, fj, keep = get3DSeg.load_csv(tmp_path / 'classes.csv')
+    assert cid == [86, 114, 3] and pid == [1, 2, 5] and keep == [86, 114] and pname[0] == 'wall'
+
+
+def test_out_of_scope_entry_points_fail_loudly():
+    from Fusion3DSeg.process3D import process3DSeg
+    from Fusion3DSeg.fusion import Fusion
+    with pytest.raises(NotImplementedError):
+        process3DSeg('in', 'out')
+    with pytest.raises(NotImplementedError):
+        Fusion('tof', 'rts')

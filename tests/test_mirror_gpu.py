@@ -1,0 +1,212 @@
+"""The reference's call surface (Fusion3DSeg.*, RTAB_utils.*, get3DSeg, get2DSeg) running on the HIP library,
+checked against the golden vectors / the oracle.  Needs a GPU."""
+import copy
+import json
+import pickle
+
+import numpy as np
+import pytest
+
+import f3d
+from f3d import synth
+from oracle import np_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_camera_utils_and_intersections_drop_in(golden):
+    from Fusion3DSeg.camera_utils import points2pixel
+    from Fusion3DSeg.intersections import point_inside_polyhedra
+    g = golden('points2pixel')
+    uv = points2pixel(g['points'], g['K'][0], g['q_wxyz'][0], g['t'][0])
+    assert uv.dtype == np.int32 and uv.shape == (2, len(g['points']))
+    assert np.array_equal(uv, O.points2pixel(g['points'], g['K'][0], g['q_wxyz'][0], g['t'][0]))
+    gi = golden('inside_polyhedra')
+    got = point_inside_polyhedra(gi['adv_points'], gi['plane_points'][2], gi['plane_normals'][2])
+    assert got.dtype == np.bool_ and np.array_equal(got, gi['inside_adv'][2])
+
+
+def test_spatquad_drop_in(golden):
+    from RTAB_utils.spatQuad import SpatQuadranion, get_quaternion_from_euler, multiplyQuadernion
+    g = golden('rotate')
+    for q, want in zip(g['q_wxyz'], g['rotated']):
+        got = SpatQuadranion(q).rotate(g['points'])
+        assert np.array_equal(got, O.rotate(q, g['points']))
+        assert np.abs(got - want).max() <= 8 * np.finfo(float).eps * np.dot(q, q) * np.abs(g['points']).max()
+    q = SpatQuadranion([2.0, 0, 0, 0])
+    assert np.array_equal(q.inverse.elements, [0.5, 0, 0, 0])                  # Q4: un-normalised inverse
+    with pytest.raises(ZeroDivisionError):
+        SpatQuadranion([0, 0, 0, 0]).inverse
+    e = get_quaternion_from_euler(0.1, -0.2, 0.3)
+    assert abs(np.linalg.norm(e.elements) - 1) < 1e-12
+    prod = multiplyQuadernion(e, e.inverse)
+    assert np.allclose(prod.elements, [1, 0, 0, 0], atol=1e-12)
+
+
+def test_frustum_data_drop_in(golden):
+    from Fusion3DSeg.fusion import Fusion
+    g = golden('frustum')
+    w, h = g['calib_wh']
+    e, l, so, fn = Fusion._get_frustum_data(g['calib_K'], int(w), int(h), g['q_wxyz'], g['t'])
+    for got, key in ((e, 'eyes'), (l, 'lookats'), (so, 'spoke_origins'), (fn, 'face_normals')):
+        assert got.shape == g[f'calib_{key}'].shape and np.abs(got - g[f'calib_{key}']).max() <= 1e-12
+    e, l, so, fn = Fusion._get_frustum_data(g['calib_K'], int(w), int(h), g['q_wxyz'], g['t'], g['perm_ids'])
+    assert np.abs(so - g['perm_spoke_origins']).max() <= 1e-12              # eyes[ids][ids], like the reference
+
+
+def _write_frames(tmp_path, masks, luts):
+    from PIL import Image
+    md, ud = tmp_path / 'masks', tmp_path / 'fusion' / 'uv2pt'
+    md.mkdir(parents=True); ud.mkdir(parents=True)
+    for i, (m, u) in enumerate(zip(masks, luts)):
+        Image.fromarray(m).save(md / f'{i:04d}.png')
+        np.save(ud / f'{i:04d}.npy', u)
+    return md, ud
+
+
+def test_voting_segmentation_drop_in_from_files(golden, tmp_path):
+    from Fusion3DSeg.segUtils.voting import VotingSegmentation
+    g = golden('voting')
+    md, ud = _write_frames(tmp_path, g['masks'], g['uv2pt'])
+    h, w = g['masks'].shape[1:]
+    voter = VotingSegmentation(len(g['votes']), (h, w), md, ud, int(g['nclasses']))
+    votes = voter.vote(resize=True, filename=tmp_path / 'seg' / 'votes.npy')
+    assert votes.dtype == np.float64 and np.array_equal(votes, g['votes'])
+    assert np.array_equal(np.load(tmp_path / 'seg' / 'votes.npy'), g['votes'])
+    for i in range(int(g['nseg'])):
+        flt = g[f'seg{i}_filter'].tolist() if g[f'seg{i}_has_filter'] else None
+        assert np.array_equal(voter.segment(float(g[f'seg{i}_threshold']), flt), g[f'seg{i}_classes'])
+    voter.vote(resize=True)                                                   # votes accumulate across calls (:98)
+    assert np.array_equal(voter.votes, 2 * g['votes'])
+    voter.zero()
+    assert voter.votes.sum() == 0
+    again = VotingSegmentation(0, None, None, None, 0, votes_file=tmp_path / 'seg' / 'votes.npy')
+    assert np.array_equal(again.segment(0.75, None), g['segq2_classes'])      # Q2 after reload
+
+
+def test_voting_raises_indexerror_for_bad_label(tmp_path):
+    from Fusion3DSeg.segUtils.voting import VotingSegmentation
+    masks = np.full((1, 4, 4), 200, np.uint8)
+    md, ud = _write_frames(tmp_path, masks, [np.zeros(16, np.int32)])
+    voter = VotingSegmentation(5, (4, 4), md, ud, 133)
+    with pytest.raises(IndexError):
+        voter.vote()
+
+
+def test_fusion_project_vote_argmax_drop_in():
+    from Fusion3DSeg.fusion import project_vote_argmax
+    sc = synth.scene('C1', n=20000)
+    got = project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.5, [86, 114, 115])
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.5, [86, 114, 115])
+    assert np.array_equal(got, want)
+
+
+def _blobs(rng, nblobs, per, spread=6.0):
+    centres = rng.uniform(0, spread, (nblobs, 3))
+    pts = np.vstack([c + rng.normal(size=(per, 3)) * [0.5, 0.3, 0.1] for c in centres])
+    ids = np.repeat(np.arange(nblobs), per).astype(np.int64)
+    return pts, ids
+
+
+def test_points_in_obb_and_relabel_kernels():
+    rng = np.random.default_rng(4)
+    ctx = f3d.default_context()
+    pts, ids = _blobs(rng, 70, 300)
+    boxes = [O.obb_from_points(pts[ids == k]) for k in range(70)]
+    packed = np.array([np.concatenate([c, R.reshape(-1), e]) for c, R, e in boxes])
+    inside, cooc = ctx.points_in_obb(pts, packed)
+    want = np.stack([O.points_in_obb(pts, *b) for b in boxes], axis=1)
+    assert np.array_equal(inside, want)
+    assert np.array_equal(cooc, (want.astype(np.int64).T @ want.astype(np.int64)) > 0)
+    _, cooc2 = ctx.points_in_obb(pts.astype(np.float32), packed, want_bits=False)
+    want32 = np.stack([O.points_in_obb(pts.astype(np.float32).astype(np.float64), *b) for b in boxes], axis=1)
+    assert np.array_equal(cooc2, (want32.astype(np.int64).T @ want32.astype(np.int64)) > 0)
+    moved = ids.copy()
+    n = ctx.relabel(moved, 3, 1)
+    assert n == 300 and (moved == 3).sum() == 0 and (moved == 1).sum() == 600
+    assert ctx.relabel(moved, 999, 0) == 0
+
+
+def test_merge_bb_matches_oracle_control_flow(tmp_path):
+    from Fusion3DSeg.merge_intersecting_bb import merge_bb
+    rng = np.random.default_rng(9)
+    pts, ids = _blobs(rng, 14, 250, spread=3.0)
+    ids[ids == 13] = 12                                            # one instance with no points at all
+    ids[:3] = 11                                                   # a few stray points of another instance
+    info = [{'id': k, 'category_id': 86 + (k % 3), 'parent_id': k % 2, 'area': int((ids == k).sum())} for k in range(14)]
+    want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
+    got_info, got_ids = merge_bb(tmp_path, copy.deepcopy(info), ids.copy(), pts, box_fn=O.obb_from_points)
+    assert np.array_equal(got_ids, want_ids)
+    assert [d['id'] for d in got_info] == [d['id'] for d in want_info]
+    assert [d['area'] for d in got_info] == [d['area'] for d in want_info]
+    assert len(got_info) < len(info)                               # something merged
+    assert np.array_equal(np.load(tmp_path / 'panoptic_segmentation' / 'ids.npy'), want_ids)
+    saved = json.loads((tmp_path / 'panoptic_segmentation' / 'final_info.json').read_text())
+    assert [d['id'] for d in saved] == [d['id'] for d in want_info]
+
+
+def test_sem_to_mask_kernel():
+    import get2DSeg
+    rng = np.random.default_rng(5)
+    sem = (rng.normal(size=(133, 37, 53)) * 3).astype(np.float32)
+    sem[:, :4, :] *= 0.01                                            # flat logits -> max prob ~ 1/133 < 0.017 -> label 133
+    got = get2DSeg.sem_to_mask(sem, 0.017)
+    want = O.sem_logits_to_mask(sem, 0.017)
+    m = sem.max(0, keepdims=True)
+    pmax = 1.0 / np.exp((sem - m).astype(np.float64)).sum(0)
+    clear = np.abs(pmax - 0.017) > 1e-5                              # float32 exp/sum rounding band around the threshold
+    assert got.dtype == np.uint8 and np.array_equal(got[clear], want[clear].astype(np.uint8))
+    assert (got[:4] == 133).all() and (got[4:] != 133).mean() > 0.9
+    assert np.array_equal(get2DSeg.sem_to_mask(sem, 0), sem.argmax(0).astype(np.uint8))    # no thresholding
+    import torch
+    got_t = get2DSeg.sem_to_mask(torch.from_numpy(sem).cuda(), 0.017)
+    assert np.array_equal(got_t, got)
+
+
+def test_get3dseg_segment_end_to_end(tmp_path, monkeypatch):
+    """segment(): votes -> classes -> instances -> files -> parent classes -> merge_bb, on a synthetic fusion directory."""
+    import get3DSeg
+    rng = np.random.default_rng(21)
+    pts, truth = _blobs(rng, 6, 400, spread=4.0)
+    n, h, w, nframes = len(pts), 24, 32, 5
+    labels = np.array([86, 114, 115, 86, 114, 3])[truth]
+    masks, luts = [], []
+    for f in range(nframes):
+        lut = np.full(h * w, -1, np.int32)
+        sel = rng.choice(n, h * w // 2, replace=False)
+        pix = rng.choice(h * w, len(sel), replace=False)
+        lut[pix] = sel
+        mask = np.full(h * w, 133, np.uint8)
+        mask[pix] = labels[sel]
+        masks.append(mask.reshape(h, w)); luts.append(lut)
+    md, ud = _write_frames(tmp_path, masks, luts)
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    adj = np.array([np.nonzero(d2[i] < 0.35 ** 2)[0] for i in range(n)], dtype=object)
+    with open(tmp_path / 'fusion' / 'fusion_data.pkl', 'wb') as fp:
+        pickle.dump({'points': pts, 'normals': np.zeros_like(pts), 'colors': np.zeros_like(pts), 'nmerges': np.ones(n),
+                     'occurences': np.ones(n), 'nframes': nframes, 'depth_hw': (h, w)}, fp)
+    with open(tmp_path / 'fusion' / 'adj.pkl', 'wb') as fp:
+        pickle.dump(adj, fp)
+    (tmp_path / 'classes.csv').write_text('Class_ID,Parent,Parent_ID,flag_infojson,flag_objremoval\n'
+                                          '86,wall,1,1,0\n114,floor,2,1,0\n115,ceiling,3,1,0\n133,unclassified,0,1,1\n')
+    (tmp_path / 'classes_meta.json').write_text(json.dumps({'classes': ['unclassified', 'wall', 'floor', 'ceiling'],
+                                                            'colors': [[0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255]]}))
+    monkeypatch.setattr(get3DSeg, '_CLASSES_CSV', tmp_path / 'classes.csv')
+    monkeypatch.setattr(get3DSeg, '_CLASSES_META', tmp_path / 'classes_meta.json')
+    get3DSeg.segment(tmp_path, md, threshold=0.5, nclasses=133, filter_classes=[86, 114, 115], min_pts_per_inst=50, verbose=False)
+    # oracle for the arithmetic parts
+    votes = np.zeros((n, 134))
+    for m, u in zip(masks, luts):
+        O.vote_frame(votes, u, m.reshape(-1))
+    classes = O.segment(votes, 133, 0.5, [86, 114, 115])
+    assert np.array_equal(np.load(tmp_path / 'segmentation' / 'votes.npy'), votes)
+    assert np.array_equal(np.load(tmp_path / 'segmentation' / 'classes.npy'), classes)
+    assert (classes != 133).mean() > 0.3
+    info = json.loads((tmp_path / 'panoptic_segmentation' / 'final_info.json').read_text())
+    ids = np.load(tmp_path / 'panoptic_segmentation' / 'ids.npy')
+    assert len(info) >= 2 and ids.shape == (n,)
+    assert (tmp_path / 'segmentation' / 'final_pcd.ply').is_file() and (tmp_path / 'panoptic_segmentation' / 'pcd.ply').is_file()
+    # remove_classes reuses votes.npy (Q2 path) and keeps the wall/floor/ceiling points
+    remaining = get3DSeg.remove_classes(tmp_path, md, None, threshold=0.5, verbose=False)
+    cls2 = O.segment(votes, 134, 0.5, None)
+    assert np.array_equal(remaining, np.isin(cls2, [86, 114, 115]))

@@ -118,3 +118,36 @@ def test_filter_remap_table_equals_sequential_loop():
         for i, c in enumerate(flt):
             y[y == i] = c
         assert np.array_equal(tab[x], y)
+
+
+# --------------------------------------------------------------------------- C oracle == NumPy oracle, bit for bit
+def test_c_oracle_equals_numpy_oracle(golden):
+    from oracle import c_ref as Cc
+    from f3d import synth
+    g = golden('points2pixel')
+    pts = g['points']
+    for q, t in zip(g['q_wxyz'], g['t']):
+        assert np.array_equal(Cc.rotate(q, pts), O.rotate(q, pts))
+        for K in g['K']:
+            assert np.array_equal(Cc.points2pixel(pts, K, q, t), O.points2pixel(pts, K, q, t))
+    pp, pn, eyes, look = Cc.frustum_planes(g['K'][0], 720, 960, g['q_wxyz'], g['t'], 4.0)
+    wp, wn = O.frustum_planes(g['K'][0], 720, 960, g['q_wxyz'], g['t'], 4.0)
+    assert np.array_equal(pp, wp) and np.array_equal(pn, wn)
+    gi = golden('inside_polyhedra')
+    for j in range(len(gi['plane_points'])):
+        assert np.array_equal(Cc.point_inside_polyhedra(gi['adv_points'], gi['plane_points'][j], gi['plane_normals'][j]), gi['inside_adv'][j])
+    gv = golden('voting')
+    votes = np.zeros_like(gv['votes'])
+    for mask, lut in zip(gv['masks'], gv['uv2pt']):
+        Cc.vote_frame(votes, lut, mask.reshape(-1))
+    assert np.array_equal(votes, gv['votes'])
+    for i in range(int(gv['nseg'])):
+        flt = gv[f'seg{i}_filter'].tolist() if gv[f'seg{i}_has_filter'] else None
+        assert np.array_equal(Cc.segment(gv['votes'], 133, float(gv[f'seg{i}_threshold']), flt), gv[f'seg{i}_classes'])
+    sc = synth.scene('C1', n=4000, mask_kind='iid')
+    for thr, flt in [(0.5, None), (0.3, [115, 0, 86])]:
+        want, wv = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
+                                         133, thr, flt, return_votes=True)
+        got, gvv = Cc.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
+                                          133, thr, flt, return_votes=True)
+        assert np.array_equal(got, want) and np.array_equal(gvv, wv)
