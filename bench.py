@@ -98,7 +98,7 @@ def main():
 
     import torch
     import f3d
-    from f3d import synth
+    from f3d import sharding, synth
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback on the product path)')
     torch.cuda.set_device(local)
@@ -125,10 +125,8 @@ def main():
     views = torch.from_numpy(views_np).to(dev)
     masks_full = torch.empty((V, S, S), dtype=torch.uint8, device=dev)
     if world > 1:
-        if V % world:
-            raise SystemExit(f'--views {V} must be divisible by the world size {world}')
-        per = V // world
-        masks_shard = torch.from_numpy(masks_np[rank * per:(rank + 1) * per]).to(dev)
+        v0, v1 = sharding.view_bounds(V, rank, world)                # this rank "produced" (owns) the masks of views [v0, v1)
+        masks_shard = torch.from_numpy(masks_np[v0:v1]).to(dev)
     else:
         masks_full.copy_(torch.from_numpy(masks_np))
     classes = torch.empty(n, dtype=torch.int64, device=dev)
@@ -157,7 +155,7 @@ def main():
 
     def step():
         if world > 1:
-            dist.all_gather_into_tensor(masks_full.view(-1), masks_shard.view(-1))
+            sharding.all_gather_masks(dist, masks_shard, out=masks_full)     # RCCL over xGMI: the path's one exchange step
         fuse()
 
     def fence():
