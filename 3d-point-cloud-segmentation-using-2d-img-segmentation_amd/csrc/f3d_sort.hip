@@ -7,8 +7,8 @@
 // nothing in the results: every point's label depends on its own xyz only, and the kernel writes it
 // back to the caller's index through `perm`.
 //
-//   k_bbox_partial / k_bbox_final : finite bounding box of the cloud -> cell grid (<= 32767 cells)
-//   k_cell_keys    : key[i] = cell of point i, idx[i] = i                       (streaming)
+//   k_bbox_partial / k_bbox_final : finite bounding box of a strided sample of the cloud -> cubic cell grid, <= 32 per axis
+//   k_cell_keys    : key[i] = 15-bit Morton code of point i's cell, idx[i] = i  (streaming)
 //   rocprim::radix_sort_pairs on the 15/16 key bits (2 x 8-bit onesweep passes over 8 B/point)
 //   k_gather_xyz   : sorted[j] = xyz[perm[j]]     (only for the "prepared layout" entry point; the
 //                    in-step sort lets the fused kernel read xyz through perm instead)
@@ -30,9 +30,11 @@ constexpr int SB = 256;
 struct bbox6 { double lo[3], hi[3]; };
 
 template <typename T>
-__global__ __launch_bounds__(SB) void k_bbox_partial(const T* __restrict__ xyz, int64_t n, bbox6* __restrict__ partial) {
+__global__ __launch_bounds__(SB) void k_bbox_partial(const T* __restrict__ xyz, int64_t n, int64_t stride, bbox6* __restrict__ partial) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x; i < n; i += (int64_t)gridDim.x * SB) {
+    // a strided sample is enough: points outside the sampled box are clamped into the border cells, which can only cost
+    // a little coherence, never correctness
+    for (int64_t i = ((int64_t)blockIdx.x * SB + threadIdx.x) * stride; i < n; i += (int64_t)gridDim.x * SB * stride) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double x = (double)xyz[3 * i + c];
@@ -80,22 +82,17 @@ __global__ __launch_bounds__(SB) void k_bbox_final(const bbox6* __restrict__ par
             if (!(ext[c] > 1e-12)) ext[c] = 1e-12;
             vol *= ext[c];
         }
-        double cell = cbrt(vol / (double)(max_cells / 2));
-        int total;
-        for (int it = 0; it < 8; ++it) {                      // grow the cell until the grid fits
-            total = 1;
-            for (int c = 0; c < 3; ++c) {
-                int d = (int)(ext[c] / cell) + 1;
-                if (d > 1024) d = 1024;
-                g.dim[c] = d;
-                total *= d;
-            }
-            if (total <= max_cells) break;
-            cell *= 1.3;
+        // cubic cells, at most 32 per axis: the key is the 15-bit Morton code of (ix, iy, iz), so a contiguous run of
+        // sorted points is a compact 3-D block (small footprint in every view's mask, good for the per-XCD L2)
+        (void)vol; (void)max_cells;
+        double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
+        const double cell = emax / 32.0 * 1.0000001;
+        for (int c = 0; c < 3; ++c) {
+            int d = (int)(ext[c] / cell) + 1;
+            g.dim[c] = d > 32 ? 32 : d;
         }
-        if (total > max_cells) { g.dim[0] = g.dim[1] = g.dim[2] = 1; total = 1; }
         g.inv_cell = 1.0 / cell;
-        g.ncells = total + 1;                                  // last cell collects non-finite points
+        g.ncells = 32768;                                      // key space; key 32767 also collects non-finite points
         *grid = g;
     }
 }
@@ -112,8 +109,12 @@ __device__ __forceinline__ uint32_t cell_of(const T* __restrict__ p, const f3d_c
         k = k < 0 ? 0 : (k >= g.dim[c] ? g.dim[c] - 1 : k);
         idx[c] = k;
     }
-    // boustrophedon-free simple order x-major; tiles are small compared with a cell row
-    return ok ? (uint32_t)((idx[0] * g.dim[1] + idx[1]) * g.dim[2] + idx[2]) : (uint32_t)(g.ncells - 1);
+    if (!ok) return 32767u;
+    uint32_t key = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+        key |= (((uint32_t)idx[0] >> b) & 1u) << (3 * b + 2) | (((uint32_t)idx[1] >> b) & 1u) << (3 * b + 1) | (((uint32_t)idx[2] >> b) & 1u) << (3 * b);
+    return key;
 }
 
 template <typename T>
@@ -172,14 +173,16 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + L.keys_out);
     uint32_t* idx_in = reinterpret_cast<uint32_t*>(base + L.idx_in);
     const int64_t gb = (n + SB - 1) / SB;
-    const int nparts = (int)(gb < 1024 ? gb : 1024);
+    const int64_t stride = n > (1 << 18) ? n >> 18 : 1;          // inspect <= ~262k points for the bounding box
+    const int64_t sb = ((n + stride - 1) / stride + SB - 1) / SB;
+    const int nparts = (int)(sb < 1024 ? sb : 1024);
     const int gstream = (int)(gb < 8192 ? gb : 8192);
     if (dtype == F3D_F64) {
-        hipLaunchKernelGGL(k_bbox_partial<double>, dim3(nparts), dim3(SB), 0, s, (const double*)xyz, n, partial);
+        hipLaunchKernelGGL(k_bbox_partial<double>, dim3(nparts), dim3(SB), 0, s, (const double*)xyz, n, stride, partial);
         hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(SB), 0, s, partial, nparts, grid, F3D_SORT_MAX_CELLS);
         hipLaunchKernelGGL(k_cell_keys<double>, dim3(gstream), dim3(SB), 0, s, (const double*)xyz, n, grid, keys_in, idx_in);
     } else {
-        hipLaunchKernelGGL(k_bbox_partial<float>, dim3(nparts), dim3(SB), 0, s, (const float*)xyz, n, partial);
+        hipLaunchKernelGGL(k_bbox_partial<float>, dim3(nparts), dim3(SB), 0, s, (const float*)xyz, n, stride, partial);
         hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(SB), 0, s, partial, nparts, grid, F3D_SORT_MAX_CELLS);
         hipLaunchKernelGGL(k_cell_keys<float>, dim3(gstream), dim3(SB), 0, s, (const float*)xyz, n, grid, keys_in, idx_in);
     }

@@ -217,7 +217,7 @@ def main():
                    roofline=roofline)
 
     # secondary, HBM-streaming kernels of the same path (not part of `value`)
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
         uv = torch.empty((2, n), dtype=torch.int32, device=dev)
         ins = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -238,7 +238,7 @@ def main():
         del votes, cls2
         out['streaming_kernels'] = extras
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:          # reported at N=1 only
         cb, cls_cpu, pts_cpu, masks_cpu = cpu_baseline(args.cpu_sample, V, S, args.masks, flt)
         out['cpu_baseline'] = cb
         # the same sample through the HIP path must give the same labels
