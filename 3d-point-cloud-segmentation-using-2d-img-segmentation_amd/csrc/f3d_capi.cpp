@@ -434,6 +434,7 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
         (n > 0 && !xyz) || (nviews > 0 && (!views_dev || !masks)))
         return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: bad arguments");
     if (nviews > 65535) return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: at most 65535 views");
+    if ((int64_t)h * (int64_t)w >= (int64_t)1 << 31) return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: mask of %d x %d pixels is too large", h, w);
     if ((flags & F3D_FUSE_SORT) && perm) return fail(ctx, F3D_ERR_INVALID, "project_vote_argmax: F3D_FUSE_SORT and perm are exclusive");
     hipStream_t s = pick(ctx, stream);
     f3d_filter_args fa;

@@ -490,51 +490,46 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_vote_uv2pt(const int32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------
-// a9: [C, HW] float32 logits -> uint8 mask.  A block stages 64 pixels x C classes in LDS (read
-// from HBM once, 256-B coalesced rows), 4 threads per pixel: argmax (first maximum), then
-// exp(x - max) summed in class order per thread slice and combined; max softmax = 1 / sum.
+// a9: [C, HW] float32 logits -> uint8 mask (get2DSeg.py:110-118).  HBM streaming: 4*C B in, 1 B out per pixel.
+// A thread owns 4 consecutive pixels and walks the C class planes once with 16-B loads (a wave reads 1 KiB
+// contiguous per plane, 8 planes in flight): running argmax (first maximum) and an online softmax denominator
+// s = sum exp(x - m) (rescaled when the maximum moves), so the logits are read exactly once.  max prob = 1 / s.
 // ------------------------------------------------------------------------------------------
-#define F3D_SEM_PIX 64
+__device__ __forceinline__ void sem_update(float x, int c, float& m, int& mi, float& s) {
+    if (x > m) { s = s * __expf(m - x) + 1.0f; m = x; mi = c; }
+    else s += __expf(x - m);
+}
+
+template <bool VEC4>
 __global__ __launch_bounds__(F3D_BLOCK) void k_sem_to_mask(const float* __restrict__ sem, int C, int64_t hw, float conf,
                                                             int low_label, uint8_t* __restrict__ mask) {
-    extern __shared__ float tile[];                                   // [C][F3D_SEM_PIX]
-    const int tid = threadIdx.x;
-    const int64_t ntiles = (hw + F3D_SEM_PIX - 1) / F3D_SEM_PIX;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t base = t * F3D_SEM_PIX;
-        const int px = tid & (F3D_SEM_PIX - 1);
-        for (int c = tid >> 6; c < C; c += F3D_BLOCK / F3D_SEM_PIX) {
-            const int64_t g = base + px;
-            tile[c * F3D_SEM_PIX + px] = (g < hw) ? sem[(size_t)c * hw + g] : 0.0f;
-        }
-        __syncthreads();
-        // 4 threads per pixel: thread (px, part) scans classes part, part+4, ...
-        const int part = tid >> 6;
-        float best = -INFINITY; int besti = 0x7fffffff;
-        for (int c = part; c < C; c += 4) {
-            const float x = tile[c * F3D_SEM_PIX + px];
-            if (x > best) { best = x; besti = c; }
-        }
-        __shared__ float sbest[F3D_BLOCK]; __shared__ int sidx[F3D_BLOCK]; __shared__ float ssum[F3D_BLOCK];
-        sbest[tid] = best; sidx[tid] = besti;
-        __syncthreads();
-        float m = sbest[px]; int mi = sidx[px];
+    constexpr int PX = VEC4 ? 4 : 1;
+    const int64_t ngroups = (hw + PX - 1) / PX;
+    for (int64_t gidx = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; gidx < ngroups; gidx += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t px0 = gidx * PX;
+        float m[PX], s[PX]; int mi[PX];
 #pragma unroll
-        for (int q = 1; q < 4; ++q) {
-            const float ob = sbest[q * F3D_SEM_PIX + px]; const int oi = sidx[q * F3D_SEM_PIX + px];
-            if (ob > m || (ob == m && oi < mi)) { m = ob; mi = oi; }
+        for (int k = 0; k < PX; ++k) { m[k] = -INFINITY; s[k] = 0.0f; mi[k] = 0; }
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            if (VEC4) {
+                const float4 x = *reinterpret_cast<const float4*>(sem + (size_t)c * hw + px0);
+                sem_update(x.x, c, m[0], mi[0], s[0]); sem_update(x.y, c, m[PX > 1 ? 1 : 0], mi[PX > 1 ? 1 : 0], s[PX > 1 ? 1 : 0]);
+                sem_update(x.z, c, m[PX > 2 ? 2 : 0], mi[PX > 2 ? 2 : 0], s[PX > 2 ? 2 : 0]);
+                sem_update(x.w, c, m[PX > 3 ? 3 : 0], mi[PX > 3 ? 3 : 0], s[PX > 3 ? 3 : 0]);
+            } else {
+                sem_update(sem[(size_t)c * hw + px0], c, m[0], mi[0], s[0]);
+            }
         }
-        float s = 0.0f;
-        for (int c = part; c < C; c += 4) s += expf(tile[c * F3D_SEM_PIX + px] - m);
-        ssum[tid] = s;
-        __syncthreads();
-        if (part == 0 && base + px < hw) {
-            const float tot = ((ssum[px] + ssum[F3D_SEM_PIX + px]) + ssum[2 * F3D_SEM_PIX + px]) + ssum[3 * F3D_SEM_PIX + px];
-            int lab = mi;
-            if (conf != 0.0f && 1.0f / tot < conf) lab = low_label;
-            mask[base + px] = (uint8_t)lab;
+        uint8_t lab[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            int l = mi[k];
+            if (conf != 0.0f && 1.0f / s[k] < conf) l = low_label;        // softmax max < conf_threshold -> 133
+            lab[k] = (uint8_t)l;
         }
-        __syncthreads();
+        if (VEC4) *reinterpret_cast<uchar4*>(mask + px0) = make_uchar4(lab[0], lab[PX > 1 ? 1 : 0], lab[PX > 2 ? 2 : 0], lab[PX > 3 ? 3 : 0]);
+        else mask[px0] = lab[0];
     }
 }
 
@@ -745,12 +740,10 @@ hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int6
 
 hipError_t f3d_launch_sem_to_mask(const float* sem, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s) {
     if (hw <= 0) return hipSuccess;
-    const size_t lds = (size_t)c * F3D_SEM_PIX * sizeof(float);
-    if (lds > 150 * 1024) return hipErrorInvalidValue;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_sem_to_mask, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const dim3 g(grid_for(hw, F3D_SEM_PIX, F3D_GRID_CAP)), b(F3D_BLOCK);
-    hipLaunchKernelGGL(k_sem_to_mask, g, b, lds, s, sem, c, hw, conf, low_label, mask);
+    const bool vec4 = (hw % 4 == 0) && ((reinterpret_cast<uintptr_t>(sem) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
+    const dim3 b(F3D_BLOCK);
+    if (vec4) hipLaunchKernelGGL(k_sem_to_mask<true>, dim3(grid_for(hw / 4, F3D_BLOCK, F3D_GRID_CAP)), b, 0, s, sem, c, hw, conf, low_label, mask);
+    else hipLaunchKernelGGL(k_sem_to_mask<false>, dim3(grid_for(hw, F3D_BLOCK, F3D_GRID_CAP)), b, 0, s, sem, c, hw, conf, low_label, mask);
     return hipGetLastError();
 }
 

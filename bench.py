@@ -236,6 +236,46 @@ def main():
         extras['segment_votes (a8)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
                                              bytes_per_point=1080, points=ns)
         del votes, cls2
+        # a7: one frame of the uv2pt scatter vote (1024x1024 lookup, ~70 % valid, 4M points)
+        hw = S * S
+        rng = np.random.default_rng(7)
+        lut_np = rng.integers(0, ns, hw).astype(np.int32); lut_np[rng.random(hw) < 0.3] = -1
+        lut = torch.from_numpy(lut_np).to(dev)
+        votes = torch.zeros((ns, 134), dtype=torch.float64, device=dev)
+        m0 = masks_full[0].reshape(-1)
+        tk = time_kernel(torch, lambda: ctx.vote_uv2pt_dev(lut.data_ptr(), m0.data_ptr(), hw, votes.data_ptr(), ns, 134, stream.cuda_stream), 10, stream)
+        nvalid = int((lut_np != -1).sum())
+        b = 5 * hw + 16 * nvalid
+        extras['vote_uv2pt (a7, 1 frame 1024x1024)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                                            note='5 B/pixel streamed + 8 B read + 8 B write per vote at random rows (scatter: line-granular traffic is ~8x that)')
+        del votes, lut
+        # a9: logits -> mask for one 133 x 1024 x 1024 image
+        sem = torch.randn((133, S, S), dtype=torch.float32, device=dev)
+        mk = torch.empty((S, S), dtype=torch.uint8, device=dev)
+        tk = time_kernel(torch, lambda: ctx.sem_logits_to_mask_dev(sem.data_ptr(), 133, hw, 0.017, 133, mk.data_ptr(), stream.cuda_stream), 10, stream)
+        b = (133 * 4 + 1) * hw
+        extras['sem_logits_to_mask (a9, 133x1024x1024)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                                                  bytes_per_pixel=533)
+        del sem, mk
+        # a1 / a4 single-purpose streaming kernels
+        ins = torch.empty(n, dtype=torch.uint8, device=dev)
+        F = f3d.view_fields(views_np)
+        pp, pn = np.ascontiguousarray(F['plane_pt'][0]), np.ascontiguousarray(F['plane_n'][0])
+        if not args.f32:
+            tk = time_kernel(torch, lambda: ctx._check(ctx._lib.f3d_inside_polyhedra_dev(ctx._h, xyz.data_ptr(), dtype, n, pp.ctypes.data, pn.ctypes.data, 5,
+                                                                                       ins.data_ptr(), stream.cuda_stream)), 10, stream)
+            b = (xyz_b + 1) * n
+            extras['inside_polyhedra (a4, 5 planes)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                                             bytes_per_point=xyz_b + 1)
+        # a10/a11: all points x 64 oriented boxes, membership co-occurrence only
+        boxes = np.zeros((64, 15)); boxes[:, 0:3] = rng.uniform([-5, -5, 0], [5, 5, 3], (64, 3))
+        boxes[:, 3:12] = np.eye(3).reshape(-1); boxes[:, 12:15] = 0.8
+        cooc = torch.zeros((64, 64), dtype=torch.uint8, device=dev)
+        tk = time_kernel(torch, lambda: ctx.points_in_obb_dev(xyz.data_ptr(), dtype, n, boxes, None, cooc.data_ptr(), stream.cuda_stream), 5, stream)
+        extras['points_in_obb (a10/a11, 64 boxes)'] = dict(ms=round(tk * 1e3, 4), point_box_tests_per_s=round(64 * n / tk, 1),
+                                                           GBps=round(xyz_b * n / tk / 1e9, 1), hbm_frac=round(xyz_b * n / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                                           note='fp64-VALU bound beyond ~8 boxes (27 flop per point-box test); brute force over boxes')
+        del ins, cooc
         out['streaming_kernels'] = extras
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:          # reported at N=1 only
