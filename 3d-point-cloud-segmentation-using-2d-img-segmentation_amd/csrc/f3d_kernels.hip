@@ -278,31 +278,46 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
             unsigned long long in_m = __ballot(vj < nviews && box_in && !box_out);
             if (wave_odd) { out_m = 0ull; in_m = 0ull; }
             if (!wave_any) out_m = valid_m;
-            unsigned long long todo = valid_m & ~out_m;
+            // views whose planes all contain the wave's box: every live lane is inside, no cull, no divergence
+            unsigned long long todo = valid_m & ~out_m & in_m;
             while (todo) {
                 const int bit = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const int v = 64 * g + bit;
                 const f3d_view& vw = views[v];
-                bool inside = live;
-                if (!((in_m >> bit) & 1ull)) {              // mixed view: per-point float32 cull, exact test inside the margin
-                    bool maybe, sure;
-                    cull_point32(vw, px32, py32, pz32, ps32, small, maybe, sure);
-                    inside = live & maybe;
-                    if (__any(inside & !sure)) {
-                        if (inside & !sure) inside = inside_view_cold(&vw, p.x, p.y, p.z);
-                    }
+                int iu, iv;
+                bool unsure;
+                bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live;
+                if (__any(unsure & live)) {                 // canonical arithmetic decides
+                    if (unsure & live) hit = project_exact_cold(&vw, p.x, p.y, p.z, W, H, &iu, &iv);
+                }
+                if (pend) vote(pend_label);                 // retire the previous view's vote, then issue this gather
+                pend = hit;
+                if (hit) pend_label = (masks + (size_t)v * plane)[(unsigned)(iv * W + iu)];
+            }
+            // mixed views: per-point float32 cull, exact plane test inside the margin
+            todo = valid_m & ~out_m & ~in_m;
+            while (todo) {
+                const int bit = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int v = 64 * g + bit;
+                const f3d_view& vw = views[v];
+                bool maybe, sure;
+                cull_point32(vw, px32, py32, pz32, ps32, small, maybe, sure);
+                bool inside = live & maybe;
+                if (__any(inside & !sure)) {
+                    if (inside & !sure) inside = inside_view_cold(&vw, p.x, p.y, p.z);
                 }
                 bool hit = false;
                 int iu = 0, iv = 0;
                 if (inside) {
                     bool unsure;
                     hit = project_fast(vw, p, W, H, umax, iu, iv, unsure);
-                    if (__any(unsure)) {                    // canonical arithmetic decides
+                    if (__any(unsure)) {
                         if (unsure) hit = project_exact_cold(&vw, p.x, p.y, p.z, W, H, &iu, &iv);
                     }
                 }
-                if (pend) vote(pend_label);                 // retire the previous view's vote, then issue this gather
+                if (pend) vote(pend_label);
                 pend = hit;
                 if (hit) pend_label = (masks + (size_t)v * plane)[(unsigned)(iv * W + iu)];
             }
