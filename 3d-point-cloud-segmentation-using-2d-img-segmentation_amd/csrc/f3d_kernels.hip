@@ -185,7 +185,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
     uint32_t* hist = lds_u32 + 64 * F3D_CULL_ROW;                         // [words_per_thread][F3D_BLOCK]
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const int ncols = nclasses + 1;
-    const int words = (ncols + HT::per_word - 1) >> HT::shift;
+    const int words = (ncols + 1 + HT::per_word - 1) >> HT::shift;       // + 1: the spare bin of the branch-free vote
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
     const size_t plane = (size_t)H * (size_t)W;
     const int ngroups = (nviews + 63) >> 6;
@@ -242,17 +242,23 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         bool pend = false;                                  // software-pipelined gather: vote one view later
         int pend_label = 0;
 
-        auto vote = [&](int label) {
-            if (label > nclasses) { atomicOr(err, F3D_DEVERR_INDEX); return; }    // IndexError in the reference
-            ++total;
+        // branch-free vote: lanes without a pending sample vote into a spare bin (index ncols) that nothing reads, so the
+        // view loop is straight-line code (no exec-mask juggling, and the compiler may overlap the next view's loads)
+        bool bad = false;
+        auto vote = [&](bool valid, int label) {
+            bad = bad | (valid & (label > nclasses));                             // IndexError in the reference (flagged per tile)
+            valid = valid & (label <= nclasses);
+            total += valid ? 1 : 0;
             if (MODE == MODE_FILTER8) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) fc[k] += (label == flt.cls[k]) ? 1 : 0;
+                for (int k = 0; k < 8; ++k) fc[k] += (valid & (label == flt.cls[k])) ? 1 : 0;
             } else {
-                const int sh = (label & (HT::per_word - 1)) * HT::bits;
-                const uint32_t old = atomicAdd(&hist[(label >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
+                const int l = valid ? label : ncols;
+                const int sh = (l & (HT::per_word - 1)) * HT::bits;
+                const uint32_t old = atomicAdd(&hist[(l >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
                 const int c = (int)((old >> sh) & HT::mask) + 1;
-                if (c > best_c || (c == best_c && label < best_l)) { best_c = c; best_l = label; }
+                const bool better = valid & ((c > best_c) | ((c == best_c) & (l < best_l)));
+                best_c = better ? c : best_c; best_l = better ? l : best_l;
             }
         };
 
@@ -291,9 +297,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 if (__any(unsure & live)) {                 // canonical arithmetic decides
                     if (unsure & live) hit = project_exact_cold(&vw, p.x, p.y, p.z, W, H, &iu, &iv);
                 }
-                if (pend) vote(pend_label);                 // retire the previous view's vote, then issue this gather
+                vote(pend, pend_label);                     // retire the previous view's vote, then issue this gather
                 pend = hit;
-                if (hit) pend_label = (masks + (size_t)v * plane)[(unsigned)(iv * W + iu)];
+                pend_label = (masks + (size_t)v * plane)[hit ? (unsigned)(iv * W + iu) : 0u];
             }
             // mixed views: per-point float32 cull, exact plane test inside the margin
             todo = valid_m & ~out_m & ~in_m;
@@ -317,12 +323,13 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                         if (unsure) hit = project_exact_cold(&vw, p.x, p.y, p.z, W, H, &iu, &iv);
                     }
                 }
-                if (pend) vote(pend_label);
+                vote(pend, pend_label);
                 pend = hit;
-                if (hit) pend_label = (masks + (size_t)v * plane)[(unsigned)(iv * W + iu)];
+                pend_label = (masks + (size_t)v * plane)[hit ? (unsigned)(iv * W + iu) : 0u];
             }
         }
-        if (pend) vote(pend_label);
+        vote(pend, pend_label);
+        if (bad) atomicOr(err, F3D_DEVERR_INDEX);
 
         // ---- VotingSegmentation.segment (voting.py:120-135) for this point
         int64_t cls;
@@ -682,7 +689,7 @@ size_t f3d_fuse_lds_bytes(int mode, int nclasses) {
     size_t hist = 0;
     if (mode != MODE_FILTER8) {
         const int per_word = (mode == MODE_HIST8) ? 4 : 2;
-        hist = (size_t)((ncols + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);
+        hist = (size_t)((ncols + 1 + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);   // + the spare bin
     }
     return 64 * F3D_CULL_ROW * sizeof(float) + hist;
 }

@@ -289,3 +289,53 @@ def test_views_record_fast_operator_matches_canonical_rotation():
         got = d @ F['M'][j].T
         assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
         assert (F['mnorm'][j] >= np.abs(sc['K']).sum(1) * np.dot(F['qinv'][j], F['qinv'][j])).all()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE.json configurations at full size: oracle on a subset + size-independent properties
+# ------------------------------------------------------------------------------------------------------------
+def _full_size_case(ctx, name, mask_kind, flt, subset=60_000):
+    import torch
+    sc = synth.scene(name, mask_kind=mask_kind)
+    pts, n = sc['points'], len(sc['points'])
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    labels = _dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, f3d.FUSE_SORT)
+    assert labels.min() >= 0 and labels.max() <= 133
+    # (1) the oracle on a random subset agrees with the full run at those indices (labels are per-point functions)
+    rng = np.random.default_rng(123)
+    idx = rng.choice(n, subset, replace=False)
+    want = O.project_vote_argmax(pts[idx], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.5, flt)
+    assert np.array_equal(labels[idx], want)
+    # (2) sorted-in-call, caller-order and prepared-layout paths agree everywhere
+    assert np.array_equal(_dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, 0), labels)
+    assert np.array_equal(_dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, 0, presort=True), labels)
+    # (3) permutation equivariance: labelling a shuffled cloud = shuffling the labels
+    perm = rng.permutation(n)
+    assert np.array_equal(_dev_fuse(ctx, pts[perm], views, sc['masks'], flt, 0.5, f3d.FUSE_SORT), labels[perm])
+    # (4) float32 storage of the (f32-representable) cloud gives the same labels
+    assert np.array_equal(_dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, f3d.FUSE_SORT, f32=True), labels)
+    # (5) a view that sees nothing new changes nothing: appending a camera that looks away from the cloud
+    q_far, t_far = synth.ring_views(1)
+    t_far = t_far + np.array([1000.0, 0, 0])
+    views2 = f3d.views_build(sc['K'], sc['w'], sc['h'], np.vstack([sc['wxyzs'], q_far]), np.vstack([sc['translations'], t_far]), sc['max_depth'])
+    masks2 = np.concatenate([sc['masks'], np.full((1,) + sc['masks'].shape[1:], 7, np.uint8)])
+    assert np.array_equal(_dev_fuse(ctx, pts, views2, masks2, flt, 0.5, f3d.FUSE_SORT), labels)
+    return labels
+
+
+def test_config_c2_1m_points_16_rtab_views(ctx):
+    labels = _full_size_case(ctx, 'C2', 'block64', [86, 114, 115])
+    assert (labels != 133).mean() > 0.05
+
+
+def test_config_c3_10m_points_64_views(ctx):
+    labels = _full_size_case(ctx, 'C3', 'block64', None)
+    assert (labels != 133).mean() > 0.2
+
+
+def test_config_c1_full_vs_oracle(ctx):
+    sc = synth.scene('C1', mask_kind='iid')
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    for thr, flt in [(0.5, None), (0.0, None), (0.5, [86, 114, 115])]:
+        want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, thr, flt)
+        assert np.array_equal(ctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, thr, flt), want)
