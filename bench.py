@@ -194,8 +194,20 @@ def main():
     xyz_b = 12 if args.f32 else 24
     abytes = algorithmic_bytes(n, V, S, S, xyz_b)
     achieved = abytes / t_kernel / 1e9
+    traffic, traffic_src = None, None
+    pmc = ROOT / 'profiles' / 'r01_pmc_by_kernel.csv'      # PMC passes of this same command (rocprofv3 --pmc, separate runs)
+    if pmc.is_file() and n == 10_000_000 and V == 64 and S == 1024 and not args.f32:
+        vals = {}
+        for line in pmc.read_text().splitlines()[1:]:
+            k, c, v = line.split(',')
+            if k == 'k_fuse':
+                vals[c] = float(v)
+        if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+            traffic = int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
+            traffic_src = ('profiles/r01_pmc_by_kernel.csv: (FETCH_SIZE + WRITE_SIZE) KB per k_fuse launch, raw (the x2 FETCH_SIZE '
+                           'correction is calibrated for wide streams, not for 1-byte gathers; L2 misses incl. Infinity-Cache hits)')
     roofline = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     kernel='k_fuse', kernel_ms=round(t_kernel * 1e3, 4), sort_ms=round(t_sort * 1e3, 4),
                     algorithmic_bytes=abytes,
                     valu_frac=round(FLOP_PER_POINT_VIEW * n * V / t_kernel / (FP64_VALU_PEAK_TFLOPS * 1e12), 4),
