@@ -62,28 +62,99 @@ def update_id_info(id1, int_bb, info_sem, id_info_per_point):
     return info_sem, id_info_per_point
 
 
-def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, info_sem, box_fn=obb_from_points):
-    """Ids (list indices) whose box shares a cloud point with the box of id1 (reference :68-91)."""
-    own = pcd_points[id_info_per_point == id1]
-    if len(own) < 4:
+class _MergeState:
+    """Book-keeping that turns the reference's O(B^2) full-cloud rescans into exact incremental updates:
+    member index lists per id (kept in ascending point order, so every box is fitted on exactly the array
+    ``pcd_points[ids == id]`` the reference would build), cached boxes with their axis-aligned bounds, and the
+    cloud resident on the GPU for the whole merge."""
+
+    def __init__(self, pts, ids, box_fn):
+        self.pts, self.ids, self.box_fn = pts, ids, box_fn
+        order = np.argsort(ids, kind='stable')
+        uniq, start = np.unique(ids[order], return_index=True)
+        bounds = np.append(start, len(order))
+        self.members = {int(u): order[bounds[k]:bounds[k + 1]] for k, u in enumerate(uniq)}
+        self.boxes = {}
+        self.ctx = f3d.default_context()
+        self.dev = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                self.torch = torch
+                self.device = torch.device('cuda', self.ctx.device)
+                self.dev = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)).to(self.device)
+                self.stream = torch.cuda.Stream(self.device)
+        except ImportError:
+            pass
+
+    def count(self, i):
+        m = self.members.get(int(i))
+        return 0 if m is None else len(m)
+
+    def box(self, i):
+        """(center, R, extent, aabb_lo, aabb_hi) of instance i, refitted only after its membership changed."""
+        i = int(i)
+        if i not in self.boxes:
+            c, R, e = self.box_fn(self.pts[self.members[i]])
+            corners = obb_corners(c, R, e)
+            pad = 1e-9 * (np.abs(corners).max() + np.abs(e).max() + 1.0)       # the in-box test rounds; never prune a touching pair
+            self.boxes[i] = (c, R, e, corners.min(0) - pad, corners.max(0) + pad)
+        return self.boxes[i]
+
+    def absorb(self, dst, src):
+        """update_id_info's relabel (reference :59-61) on the incremental state."""
+        dst, src = int(dst), int(src)
+        moved = self.members.pop(src, None)
+        if moved is None or not len(moved):
+            return
+        self.ids[moved] = dst
+        cur = self.members.get(dst)
+        self.members[dst] = np.sort(moved) if cur is None else np.sort(np.concatenate([cur, moved]))
+        self.boxes.pop(dst, None)
+        self.boxes.pop(src, None)
+
+    def shares_point(self, box1, others):
+        """For each box in `others`: does some cloud point lie in both it and box1?  One launch over the cloud."""
+        hits = np.zeros(len(others), bool)
+        for s in range(0, len(others), f3d.MAX_OBB - 1):
+            part = [box1] + others[s:s + f3d.MAX_OBB - 1]
+            packed = _pack([(b[0], b[1], b[2]) for b in part])
+            if self.dev is None:
+                _, cooc = self.ctx.points_in_obb(self.pts, packed, want_bits=False, want_cooc=True)
+            else:
+                torch = self.torch
+                with torch.cuda.stream(self.stream):
+                    cd = torch.empty((len(part), len(part)), dtype=torch.uint8, device=self.device)
+                    self.ctx.points_in_obb_dev(self.dev.data_ptr(), f3d.F64, len(self.pts), packed, None, cd.data_ptr(),
+                                               self.stream.cuda_stream)
+                    self.stream.synchronize()
+                    cooc = cd.cpu().numpy().astype(bool)
+            hits[s:s + len(part) - 1] = cooc[0, 1:]
+        return hits
+
+
+def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, info_sem, box_fn=obb_from_points, state=None):
+    """Ids (list indices) whose box shares a cloud point with the box of id1 (reference :68-91).
+
+    Same decisions as the reference, fewer scans: a partner whose box's axis-aligned bounds do not touch those of
+    id1's box cannot share a point with it, so only the touching partners are tested on the GPU (exact pruning)."""
+    st = state if state is not None else _MergeState(pcd_points, id_info_per_point, box_fn)
+    if st.count(id1) < 4:
         return []
-    boxes, cand = [box_fn(own)], []
+    box1 = st.box(id1)
+    cand = []
     for id2 in range(1, len(id_list)):
         if id1 != id2 and id2 < len(info_sem) - 1 and id1 < len(info_sem) - 1:
             if info_sem[id1]["parent_id"] == info_sem[id2]["parent_id"]:
-                other = pcd_points[id_info_per_point == id2]
-                if len(other) < 4:
+                if st.count(id2) < 4:
                     break                                  # the reference returns what it has so far (:83-84)
-                boxes.append(box_fn(other))
-                cand.append(id2)
+                b2 = st.box(id2)
+                if (box1[3] <= b2[4]).all() and (b2[3] <= box1[4]).all():
+                    cand.append(id2)
     if not cand:
         return []
-    hits = []
-    for s in range(0, len(cand), f3d.MAX_OBB - 1):        # box 0 (id1) + up to 4095 candidates per launch
-        part = [boxes[0]] + boxes[1 + s:1 + s + f3d.MAX_OBB - 1]
-        _, cooc = f3d.default_context().points_in_obb(pcd_points, _pack(part), want_bits=False, want_cooc=True)
-        hits += [cand[s + k] for k in np.nonzero(cooc[0, 1:])[0]]
-    return hits
+    hit = st.shares_point(box1, [st.box(c) for c in cand])
+    return [c for c, h in zip(cand, hit) if h]
 
 
 def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=obb_from_points):
@@ -92,18 +163,21 @@ def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=obb_from_points)
     pts = np.ascontiguousarray(np.asarray(pcd.points if hasattr(pcd, 'points') else pcd), dtype=np.float64)
     t0 = time.perf_counter()
     id_list = [info_sem[i]["id"] for i in range(len(info_sem))]
+    st = _MergeState(pts, id_info_per_point, box_fn)
     for id1 in range(1, len(id_list)):
-        hits = check_intersection_open3d(id1, id_list, id_info_per_point, pts, pcd, info_sem, box_fn)
+        hits = check_intersection_open3d(id1, id_list, id_info_per_point, pts, pcd, info_sem, box_fn, st)
         if hits:
             for b in hits:
-                info_sem, id_info_per_point = update_id_info(id1, b, info_sem, id_info_per_point)
+                info_sem[id1]["area"] += info_sem[b]["area"]       # update_id_info (:58-62)
+                st.absorb(id1, b)
             for b in hits:
                 if b < len(info_sem):
                     del info_sem[b]
     for k in range(1, len(info_sem)):
-        own = pts[id_info_per_point == info_sem[k]["id"]]
-        if len(own) > 4:
-            info_sem[k]["bbox"] = obb_corners(*box_fn(own)).tolist()
+        i = info_sem[k]["id"]
+        if st.count(i) > 4:
+            c, R, e = st.box(i)[:3]
+            info_sem[k]["bbox"] = obb_corners(c, R, e).tolist()
     print(f'Time taken for merging {n0} to {len(info_sem)} Bounding boxes = {time.perf_counter() - t0} seconds')
     if dir_name is not None:
         out = Path(dir_name) / "panoptic_segmentation"

@@ -210,3 +210,23 @@ def test_get3dseg_segment_end_to_end(tmp_path, monkeypatch):
     remaining = get3DSeg.remove_classes(tmp_path, md, None, threshold=0.5, verbose=False)
     cls2 = O.segment(votes, 134, 0.5, None)
     assert np.array_equal(remaining, np.isin(cls2, [86, 114, 115]))
+
+
+@pytest.mark.parametrize('seed,nblobs,spread', [(31, 40, 4.0), (32, 60, 9.0)])
+def test_merge_bb_randomised_against_oracle(seed, nblobs, spread):
+    from Fusion3DSeg.merge_intersecting_bb import merge_bb
+    rng = np.random.default_rng(seed)
+    pts, ids = _blobs(rng, nblobs, 120, spread=spread)
+    small = rng.choice(np.arange(5, nblobs), 4, replace=False)           # instances with < 4 points: early return (:83-84)
+    for s_ in small:
+        idx = np.nonzero(ids == s_)[0]
+        ids[idx[2:]] = int(rng.integers(1, 5))
+    info = [{'id': k, 'category_id': 86, 'parent_id': int(rng.integers(0, 3)), 'area': int((ids == k).sum())} for k in range(nblobs)]
+    want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
+    got_info, got_ids = merge_bb(None, copy.deepcopy(info), ids.copy(), pts, box_fn=O.obb_from_points)
+    assert np.array_equal(got_ids, want_ids)
+    assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info]
+    for g, w in zip(got_info, want_info):
+        assert ('bbox' in g) == ('bbox' in w)
+        if 'bbox' in g:
+            assert np.allclose(g['bbox'], w['bbox'])
