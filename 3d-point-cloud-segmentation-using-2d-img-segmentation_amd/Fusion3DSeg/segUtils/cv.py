@@ -1,48 +1,37 @@
-"""``split_into_instances`` of the reference's Fusion3DSeg/segUtils/cv.py (:402-500), host implementation.
+"""``split_into_instances`` of the reference's Fusion3DSeg/segUtils/cv.py (:402-500) on the GPU.
 
-This stage sits between voting and box merging (scope table row (f)#1, "next"): it is not a GPU kernel yet.  The
-reference flood-fills with a Python list queue; here each flood fill is a level-synchronous BFS over a CSR copy of
-the adjacency with NumPy frontiers -- same reachability, same processing order (classes in the given order, seed =
-lowest remaining index), hence identical ids, info records and updated classes (pinned by tests/golden).
+The reference flood-fills, class by class, from the lowest remaining point index through same-class neighbours
+(a Python list queue).  Here the flood fill is one GPU pass (f3d_components_same_class: lock-free union-find over the
+CSR adjacency, every component rooted at its smallest index); the numbering that follows -- classes in the given
+order, components by ascending seed, small clusters folded into one "unclassified" bucket created on first use -- is
+reproduced with array operations, so ids, info records and updated classes are identical to the reference's
+(pinned by tests/golden/split_instances.npz).
+
+One stated difference: the adjacency is used as an undirected graph.  The reference follows neighbour lists as
+directed edges; the two coincide for symmetric lists, which is what ``KDTree.query_radius`` (the only producer,
+fusion.py:369-377) returns.
 """
 import numpy as np
 
+import f3d
 
-def _csr(adj, n):
+
+def adjacency_to_csr(adj, n):
+    """list / object array of neighbour index arrays -> (offsets int64 [n+1], neighbours int32 [E])."""
     lens = np.fromiter((len(a) for a in adj), dtype=np.int64, count=n)
     offs = np.zeros(n + 1, np.int64)
     np.cumsum(lens, out=offs[1:])
-    flat = np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a in adj]) if n and offs[-1] else np.zeros(0, np.int64)
-    return offs, flat
-
-
-def _reach(seed, seed_class, classes, offs, flat, visited):
-    """Points of `seed_class` reachable from `seed` through same-class points (the reference's floodfill)."""
-    visited[seed] = True
-    frontier = np.array([seed], np.int64)
-    parts = []
-    while len(frontier):
-        frontier = frontier[classes[frontier] == seed_class]
-        if not len(frontier):
-            break
-        parts.append(frontier)
-        starts, ends = offs[frontier], offs[frontier + 1]
-        total = int((ends - starts).sum())
-        if not total:
-            break
-        idx = np.repeat(starts - np.concatenate([[0], np.cumsum(ends - starts)[:-1]]), ends - starts) + np.arange(total)
-        nb = np.unique(flat[idx])
-        nb = nb[~visited[nb]]
-        visited[nb] = True
-        frontier = nb
-    return np.concatenate(parts) if parts else np.zeros(0, np.int64)
+    if n == 0 or offs[-1] == 0:
+        return offs, np.zeros(0, np.int32)
+    return offs, np.concatenate([np.asarray(a).reshape(-1) for a in adj]).astype(np.int32)
 
 
 def split_into_instances(classes, adj, nclasses=133, instance_classes=None, minimum_points=1, verbose=False):
     """-> (instance ids [M], point ids [N], info list, updated classes [N]); see the reference docstring (:402-424)."""
     n = len(classes)
     classes = np.array(classes).copy()
-    offs, flat = _csr(adj, n)
+    offs, nbrs = adjacency_to_csr(adj, n)
+    ctx = f3d.default_context()
     allclasses = np.unique(classes)
     ids = np.zeros_like(classes)
     info, small_id = [], None
@@ -62,32 +51,44 @@ def split_into_instances(classes, adj, nclasses=133, instance_classes=None, mini
         if c == nclasses:
             small_id = k
         info.append({'id': k, 'isthing': False, 'category_id': int(c), 'area': int(m.sum())})
+
+    root = ctx.components_same_class(classes, offs, nbrs) if n else np.zeros(0, np.int64)
+    relabelled = False                                           # some cluster's class was rewritten since `root` was computed
     for c in instance_classes:
         if verbose:
             print('splitting class:', c)
-        remaining = classes == c
-        order = np.nonzero(remaining)[0]
-        cursor = 0
-        while cursor < len(order):
-            seed = order[cursor]
-            if not remaining[seed]:
-                cursor += 1
-                continue
-            cluster = _reach(seed, classes[seed], classes, offs, flat, np.zeros(n, bool))
-            area = len(cluster)
-            if area < minimum_points:
-                cat = nclasses
-                if small_id is None:
-                    small_id = ninst
-                    info.append({'id': ninst, 'isthing': True, 'category_id': int(cat), 'area': 0})
-                    ninst += 1
-                info[small_id]['area'] += area
-                ids[cluster] = small_id
+        if relabelled and c == nclasses:                         # folded clusters now belong to this class: flood again
+            root = ctx.components_same_class(classes, offs, nbrs)
+            relabelled = False
+        pts = np.nonzero(classes == c)[0]
+        if not len(pts):
+            continue
+        seeds, inv, sizes = np.unique(root[pts], return_inverse=True, return_counts=True)      # ascending seed = visit order
+        big = sizes >= minimum_points
+        rank = np.cumsum(big) - 1                                # running index among the kept clusters
+        comp_id = ninst + rank
+        nbig = int(big.sum())
+        if not big.all():
+            first_small = int(np.argmax(~big))
+            if small_id is None:                                 # the bucket takes the next id at its first use (:483-487)
+                small_id = ninst + int(big[:first_small].sum())
+                comp_id = comp_id + (np.arange(len(seeds)) > first_small)
+                new_small = True
             else:
-                cat = c
-                info.append({'id': ninst, 'isthing': True, 'category_id': int(cat), 'area': int(area)})
-                ids[cluster] = ninst
-                ninst += 1
-            remaining[cluster] = False
-            classes[cluster] = cat
+                new_small = False
+            comp_id = np.where(big, comp_id, small_id)
+        else:
+            new_small = False
+        # info records in id order: kept clusters, with the bucket's record spliced in where it was created
+        recs = [{'id': int(i), 'isthing': True, 'category_id': int(c), 'area': int(a)} for i, a in zip(comp_id[big], sizes[big])]
+        if new_small:
+            pos = int(small_id - ninst)
+            recs.insert(pos, {'id': int(small_id), 'isthing': True, 'category_id': int(nclasses), 'area': 0})
+        info.extend(recs)
+        if not big.all():
+            info[small_id]['area'] += int(sizes[~big].sum())
+            classes[pts[~big[inv]]] = nclasses                   # folded clusters become "unclassified" (:482,499)
+            relabelled = True
+        ids[pts] = comp_id[inv]
+        ninst += nbig + (1 if new_small else 0)
     return np.arange(ninst), ids, info, classes

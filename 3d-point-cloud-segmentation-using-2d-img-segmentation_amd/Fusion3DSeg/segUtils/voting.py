@@ -86,7 +86,11 @@ class VotingSegmentation:
             mask = np.ascontiguousarray(mask).reshape(-1)
             if (np.asarray(uv2pt) != -1).any():
                 session.add_frame(uv2pt, mask)
-        self.votes = session.download()
+        try:
+            self.votes = session.download()
+        except IndexError:
+            self.votes = session.download(check=False)      # frames before the offending one stay applied, as in the reference
+            raise
         if filename is not None:
             Path(filename).parent.mkdir(exist_ok=True, parents=True)
             np.save(filename, self.votes)
@@ -135,10 +139,14 @@ class _DeviceVotes:
             dm = torch.from_numpy(m).to(self.dev)
             self.ctx.vote_uv2pt_dev(dl.data_ptr(), dm.data_ptr(), len(lut), self.t.data_ptr(), self.t.shape[0], self.t.shape[1],
                                     self.stream.cuda_stream)
-            self.ctx.take_device_error(self.stream.cuda_stream)     # IndexError here; the frame wrote nothing
+            # no per-frame synchronisation: an out-of-range index sets a sticky device flag, the offending frame and every
+            # later one write nothing, and download() raises the IndexError -- the same votes state as the reference's
+            # exception at that frame (voting.py:98)
 
-    def download(self):
+    def download(self, check=True):
         if self.torch is None:
             return self.host
         self.stream.synchronize()
+        if check:
+            self.ctx.take_device_error(self.stream.cuda_stream)     # IndexError for the first bad frame, if any
         return self.t.cpu().numpy()

@@ -674,4 +674,41 @@ int f3d_relabel(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
     return F3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// (f)#1 same-class connected components
+// ---------------------------------------------------------------------------------------------
+int f3d_components_same_class_dev(f3d_ctx* ctx, const int64_t* classes, int64_t n, const int64_t* offsets, const int32_t* nbrs,
+                                  int32_t* parent, int64_t* root, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || n > 0x7fffffffLL || (n > 0 && (!classes || !offsets || !parent || !root)))
+        return fail(ctx, F3D_ERR_INVALID, "components_same_class: bad arguments (n < 2^31)");
+    F3D_HIP(ctx, f3d_launch_components(classes, n, offsets, nbrs, parent, root, ctx->dev_err, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_components_same_class(f3d_ctx* ctx, const int64_t* classes, int64_t n, const int64_t* offsets, const int32_t* nbrs,
+                              int64_t* root) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!classes || !offsets || !root))) return fail(ctx, F3D_ERR_INVALID, "components_same_class: bad arguments");
+    if (n == 0) return F3D_OK;
+    const int64_t e = offsets[n];
+    if (e < 0 || (e > 0 && !nbrs)) return fail(ctx, F3D_ERR_INVALID, "components_same_class: bad adjacency");
+    void *dcls, *doffs, *dnb, *dpar, *droot;
+    if ((rc = ensure(ctx, SLOT_XYZ, (size_t)n * 8, &dcls))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT1, (size_t)(n + 1) * 8, &doffs))) return rc;
+    if ((rc = ensure(ctx, SLOT_MASKS, (size_t)e * 4, &dnb))) return rc;
+    if ((rc = ensure(ctx, SLOT_AUX0, (size_t)n * 4, &dpar))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 8, &droot))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dcls, classes, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(doffs, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (e) F3D_HIP(ctx, hipMemcpyAsync(dnb, nbrs, (size_t)e * 4, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_components_same_class_dev(ctx, (const int64_t*)dcls, n, (const int64_t*)doffs, (const int32_t*)dnb, (int32_t*)dpar,
+                                            (int64_t*)droot, s))) return rc;
+    if ((rc = take_error(ctx, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(root, droot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
 }  // extern "C"

@@ -49,6 +49,9 @@ hipError_t f3d_launch_fastpath_audit(const void* xyz, int dtype, int64_t n, cons
 // cell sort (f3d_sort.hip): perm (and sorted_xyz unless NULL) receive the cloud in grid-cell order; scratch >= f3d_sort_scratch_bytes(n)
 size_t f3d_sort_scratch_bytes(int64_t n);
 hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sorted_xyz, int32_t* perm, void* scratch, hipStream_t s);
+// same-class connected components (f3d_cc.hip): root[i] = smallest index of i's component; parent = int32 [n] scratch
+hipError_t f3d_launch_components(const int64_t* classes, int64_t n, const int64_t* offs, const int32_t* nbrs, int32_t* parent,
+                                 int64_t* root, int* err, hipStream_t s);
 hipError_t f3d_launch_segment_votes(const double* votes, int64_t npts, int ncols, int nclasses, double threshold,
                                     const f3d_filter_args& flt, int64_t* classes, hipStream_t s);
 hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols,

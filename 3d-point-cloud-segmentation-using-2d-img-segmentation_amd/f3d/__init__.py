@@ -92,6 +92,8 @@ def library():
         'f3d_points_in_obb_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, vp, vp]),
         'f3d_relabel': (i32, [vp, vp, i64, i64, i64, vp]),
         'f3d_relabel_dev': (i32, [vp, vp, i64, i64, i64, vp, vp]),
+        'f3d_components_same_class': (i32, [vp, vp, i64, vp, vp, vp]),
+        'f3d_components_same_class_dev': (i32, [vp, vp, i64, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
@@ -330,6 +332,17 @@ class Context:
         cnt = np.zeros(1, np.int64)
         self._check(self._lib.f3d_relabel(self._h, _ptr(ids), ids.size, int(from_id), int(to_id), _ptr(cnt)))
         return int(cnt[0])
+
+    def components_same_class(self, classes, offsets, neighbours):
+        """root[i] = smallest index of point i's same-class connected component (CSR adjacency, symmetric)."""
+        cls = np.ascontiguousarray(classes, dtype=np.int64)
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        nb = np.ascontiguousarray(neighbours, dtype=np.int32)
+        if len(offs) != len(cls) + 1 or (len(cls) and offs[-1] != len(nb)):
+            raise ValueError('offsets must have n+1 entries ending at len(neighbours)')
+        root = np.empty(len(cls), np.int64)
+        self._check(self._lib.f3d_components_same_class(self._h, _ptr(cls), len(cls), _ptr(offs), _ptr(nb), _ptr(root)))
+        return root
 
     # ---------------------------------------------------------------- device-pointer calls
     def project_vote_argmax_dev(self, xyz_ptr, dtype, n, views_ptr, nviews, masks_ptr, h, w, nclasses, threshold,

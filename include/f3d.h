@@ -218,6 +218,17 @@ int f3d_relabel(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
 int f3d_relabel_dev(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
                     int64_t* count_dev, void* stream);
 
+/* ---- (f)#1: flood fill of split_into_instances (Fusion3DSeg/segUtils/cv.py:425-440) ------ */
+/* Connected components of the adjacency (CSR: offsets int64 [n+1], neighbours int32 [offsets[n]]) restricted to
+ * edges whose end points have the same class; root[i] = smallest point index of i's component (= the seed the
+ * reference's "lowest remaining index" rule picks).  The adjacency must be symmetric, as KDTree.query_radius
+ * (fusion.py:369-377) produces it.  A neighbour index outside [0, n) -> F3D_ERR_INDEX. */
+int f3d_components_same_class(f3d_ctx* ctx, const int64_t* classes, int64_t n, const int64_t* offsets,
+                              const int32_t* neighbours, int64_t* root);
+int f3d_components_same_class_dev(f3d_ctx* ctx, const int64_t* classes, int64_t n, const int64_t* offsets,
+                                  const int32_t* neighbours, int32_t* parent_scratch /*int32 [n]*/, int64_t* root,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

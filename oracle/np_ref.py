@@ -397,3 +397,67 @@ def merge_bb(info_sem, ids, points, box_fn=obb_from_points):
         if len(own) > 4:
             info_sem[k]["bbox"] = obb_corners(*box_fn(own)).tolist()
     return info_sem, ids
+
+
+# ----------------------------------------------------------------------------
+# (f)#1  split_into_instances (segUtils/cv.py:402-500), literal restatement
+# ----------------------------------------------------------------------------
+def split_into_instances(classes, adj, nclasses=133, instance_classes=None, minimum_points=1):
+    """Flood fill from the lowest remaining index through same-class neighbours (directed neighbour lists, FIFO
+    queue), clusters numbered in visit order, small ones folded into one bucket -- cv.py:425-500 line by line."""
+    n = len(classes)
+    classes = np.array(classes).copy()
+    allclasses = np.unique(classes)
+    ids = np.zeros_like(classes)
+    info, small_id = [], None
+    if instance_classes is None:
+        instance_classes, semantic_classes, ninst = allclasses, [], 0
+        if (instance_classes == nclasses).any():
+            instance_classes = instance_classes[instance_classes != nclasses]
+            semantic_classes, ninst = [nclasses], 1
+    else:
+        instance_classes = np.array(instance_classes)
+        semantic_classes = np.setdiff1d(allclasses, instance_classes)
+        ninst = len(semantic_classes)
+    for k in range(ninst if len(semantic_classes) else 0):
+        c = semantic_classes[k]
+        m = classes == c
+        ids[m] = k
+        if c == nclasses:
+            small_id = k
+        info.append({'id': k, 'isthing': False, 'category_id': int(c), 'area': int(m.sum())})
+    for c in instance_classes:
+        mask = classes == c
+        remaining = np.nonzero(mask)[0]
+        while len(remaining):
+            seed = remaining[0]
+            seed_class = classes[seed]
+            inq = np.zeros(n, bool)
+            inq[seed] = True
+            queue, cluster, head = [seed], [], 0
+            while head < len(queue):
+                pnt = queue[head]; head += 1
+                if classes[pnt] != seed_class:
+                    continue
+                cluster.append(pnt)
+                new = [q for q in adj[pnt] if not inq[q]]
+                queue += new
+                inq[new] = True
+            cluster = np.array(cluster)
+            if len(cluster) < minimum_points:
+                cat = nclasses
+                if small_id is None:
+                    small_id = ninst
+                    info.append({'id': ninst, 'isthing': True, 'category_id': int(cat), 'area': 0})
+                    ninst += 1
+                info[small_id]['area'] += len(cluster)
+                ids[cluster] = small_id
+            else:
+                cat = c
+                info.append({'id': ninst, 'isthing': True, 'category_id': int(cat), 'area': int(len(cluster))})
+                ids[cluster] = ninst
+                ninst += 1
+            mask[cluster] = False
+            remaining = np.nonzero(mask)[0]
+            classes[cluster] = cat
+    return np.arange(ninst), ids, info, classes

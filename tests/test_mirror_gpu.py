@@ -230,3 +230,50 @@ def test_merge_bb_randomised_against_oracle(seed, nblobs, spread):
         assert ('bbox' in g) == ('bbox' in w)
         if 'bbox' in g:
             assert np.allclose(g['bbox'], w['bbox'])
+
+
+def _info_rows(info):
+    return np.array([[d['id'], int(d['isthing']), d['category_id'], d['area']] for d in info], np.int64).reshape(-1, 4)
+
+
+def test_split_into_instances_gpu_matches_reference_golden(golden):
+    from Fusion3DSeg.segUtils.cv import split_into_instances
+    g = golden('split_instances')
+    offs, flat = g['adj_offsets'], g['adj_flat']
+    adj = [flat[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    for i in range(int(g['ncases'])):
+        ic = g[f'case{i}_instance_classes'].tolist() if g[f'case{i}_has_instance_classes'] else None
+        insts, ids, info, newcls = split_into_instances(g['classes'], adj, 133, ic, int(g[f'case{i}_minimum_points']))
+        assert len(insts) == int(g[f'case{i}_ninst']), i
+        assert np.array_equal(ids, g[f'case{i}_ids']), i
+        assert np.array_equal(newcls, g[f'case{i}_classes']), i
+        assert np.array_equal(_info_rows(info), g[f'case{i}_info']), i
+
+
+@pytest.mark.parametrize('ic,minpts', [(None, 1), (None, 6), ([86, 114], 4), ([3, 133, 86], 5), ([133], 1)])
+def test_split_into_instances_gpu_matches_oracle_random(ic, minpts):
+    from Fusion3DSeg.segUtils.cv import split_into_instances
+    rng = np.random.default_rng(17)
+    n = 6000
+    xy = rng.uniform(0, 30, (n, 3)) * [1, 1, 0.05]
+    from scipy.spatial import cKDTree
+    adj = cKDTree(xy).query_ball_point(xy, r=0.55)                       # symmetric radius graph, self included
+    classes = rng.choice([86, 114, 115, 133, 3], n, p=[0.3, 0.25, 0.2, 0.15, 0.1]).astype(np.int64)
+    want = O.split_into_instances(classes, adj, 133, ic, minpts)
+    got = split_into_instances(classes, adj, 133, ic, minpts)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
+    assert np.array_equal(_info_rows(got[2]), _info_rows(want[2]))
+    assert len(want[0]) > 10
+
+
+def test_components_kernel_long_chains_and_bad_index():
+    ctx = f3d.default_context()
+    n = 200_000                                                          # one long path: worst case for label propagation
+    offs = np.arange(0, 2 * n + 1, 2, dtype=np.int64)
+    nb = np.stack([np.maximum(np.arange(n) - 1, 0), np.minimum(np.arange(n) + 1, n - 1)], axis=1).reshape(-1).astype(np.int32)
+    cls = np.zeros(n, np.int64); cls[n // 2] = 7                         # cut the path in the middle
+    root = ctx.components_same_class(cls, offs, nb)
+    assert (root[:n // 2] == 0).all() and root[n // 2] == n // 2 and (root[n // 2 + 1:] == n // 2 + 1).all()
+    nb[5] = n + 3
+    with pytest.raises(IndexError):
+        ctx.components_same_class(cls, offs, nb)
