@@ -675,6 +675,110 @@ int f3d_relabel(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
 }
 
 // ---------------------------------------------------------------------------------------------
+// a12 remaining intersections.py primitives (host pointers)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct dbuf { void* p; };
+int up(f3d_ctx* ctx, int slot, const void* src, size_t bytes, void** dst) {
+    int rc = ensure(ctx, slot, bytes, dst); if (rc) return rc;
+    if (bytes) F3D_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return F3D_OK;
+}
+int down(f3d_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes) F3D_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return F3D_OK;
+}
+}  // namespace
+
+int f3d_ray_x_lines(f3d_ctx* ctx, const double origin[3], const double direction[3], const double* starts, const double* ends, int64_t n,
+                    double* points, uint8_t* within) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !origin || !direction || (n > 0 && (!starts || !ends || !points || !within))) return fail(ctx, F3D_ERR_INVALID, "ray_x_lines: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *ds, *de, *dp, *dw;
+    if ((rc = up(ctx, SLOT_XYZ, starts, (size_t)n * 24, &ds)) || (rc = up(ctx, SLOT_OUT1, ends, (size_t)n * 24, &de))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 24, &dp)) || (rc = ensure(ctx, SLOT_AUX1, (size_t)n, &dw))) return rc;
+    F3D_HIP(ctx, f3d_launch_ray_x_lines(origin, direction, (const double*)ds, (const double*)de, n, (double*)dp, (uint8_t*)dw, ctx->stream));
+    if ((rc = down(ctx, points, dp, (size_t)n * 24)) || (rc = down(ctx, within, dw, (size_t)n))) return rc;
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+int f3d_rays_x_plane(f3d_ctx* ctx, const double pp[3], const double pn[3], const double* origins, const double* dirs, int64_t n, double* points,
+                     uint8_t* valid) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !pp || !pn || (n > 0 && (!origins || !dirs || !points || !valid))) return fail(ctx, F3D_ERR_INVALID, "rays_x_plane: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *d_o, *dd, *dp, *dv;
+    if ((rc = up(ctx, SLOT_XYZ, origins, (size_t)n * 24, &d_o)) || (rc = up(ctx, SLOT_OUT1, dirs, (size_t)n * 24, &dd))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 24, &dp)) || (rc = ensure(ctx, SLOT_AUX1, (size_t)n, &dv))) return rc;
+    F3D_HIP(ctx, f3d_launch_rays_x_plane(pp, pn, (const double*)d_o, (const double*)dd, n, (double*)dp, (uint8_t*)dv, ctx->stream));
+    if ((rc = down(ctx, points, dp, (size_t)n * 24)) || (rc = down(ctx, valid, dv, (size_t)n))) return rc;
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+int f3d_lines_x_planes(f3d_ctx* ctx, const double* lo, const double* le, int64_t n, const double* pps, const double* pns, int m, double* points,
+                       uint8_t* valid) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || m < 0 || (n > 0 && (!lo || !le)) || (m > 0 && (!pps || !pns)) || (n > 0 && m > 0 && (!points || !valid)))
+        return fail(ctx, F3D_ERR_INVALID, "lines_x_planes: bad arguments");
+    if (n != 1 && n != m) return fail(ctx, F3D_ERR_INVALID, "operands could not be broadcast together with shapes (%lld,%d,3) (%lld,3)", (long long)n, m, (long long)n);
+    if (n == 0 || m == 0) return F3D_OK;
+    void *d_o, *de, *dpp, *dpn, *dp, *dv;
+    if ((rc = up(ctx, SLOT_XYZ, lo, (size_t)n * 24, &d_o)) || (rc = up(ctx, SLOT_OUT1, le, (size_t)n * 24, &de))) return rc;
+    if ((rc = up(ctx, SLOT_VIEWS, pps, (size_t)m * 24, &dpp)) || (rc = up(ctx, SLOT_AUX0, pns, (size_t)m * 24, &dpn))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * m * 24, &dp)) || (rc = ensure(ctx, SLOT_AUX1, (size_t)n * m, &dv))) return rc;
+    F3D_HIP(ctx, f3d_launch_lines_x_planes((const double*)d_o, (const double*)de, n, (const double*)dpp, (const double*)dpn, m, n == 1 ? 0 : 1,
+                                           (double*)dp, (uint8_t*)dv, ctx->stream));
+    if ((rc = down(ctx, points, dp, (size_t)n * m * 24)) || (rc = down(ctx, valid, dv, (size_t)n * m))) return rc;
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+int f3d_point_inside_polygon(f3d_ctx* ctx, const double* points, int64_t n, const double* verts, int m, uint8_t* inside, uint8_t* within) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || m < 1 || !verts || (n > 0 && (!points || !inside || !within))) return fail(ctx, F3D_ERR_INVALID, "point_inside_polygon: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *dp, *dv, *di, *dw;
+    if ((rc = up(ctx, SLOT_XYZ, points, (size_t)n * 24, &dp)) || (rc = up(ctx, SLOT_VIEWS, verts, (size_t)m * 24, &dv))) return rc;
+    if ((rc = ensure(ctx, SLOT_AUX1, (size_t)n, &di)) || (rc = ensure(ctx, SLOT_OUT0, (size_t)n * m, &dw))) return rc;
+    F3D_HIP(ctx, f3d_launch_point_inside_polygon((const double*)dp, n, (const double*)dv, m, (uint8_t*)di, (uint8_t*)dw, ctx->stream));
+    if ((rc = down(ctx, inside, di, (size_t)n)) || (rc = down(ctx, within, dw, (size_t)n * m))) return rc;
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+int f3d_points_plane_projection(f3d_ctx* ctx, const double* points, int64_t n, const double pp[3], const double nr[3], double* out) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !pp || !nr || (n > 0 && (!points || !out))) return fail(ctx, F3D_ERR_INVALID, "points_plane_projection: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *dp, *d_o;
+    if ((rc = up(ctx, SLOT_XYZ, points, (size_t)n * 24, &dp)) || (rc = ensure(ctx, SLOT_OUT0, (size_t)n * 24, &d_o))) return rc;
+    F3D_HIP(ctx, f3d_launch_points_plane_projection((const double*)dp, n, pp, nr, (double*)d_o, ctx->stream));
+    if ((rc = down(ctx, out, d_o, (size_t)n * 24))) return rc;
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+int f3d_lines_plane_projection(f3d_ctx* ctx, const double* starts, const double* ends, int64_t n, const double pp[3], const double nr[3],
+                               double* sp, double* ep, double* dirs) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !pp || !nr || (n > 0 && (!starts || !ends || !sp || !ep || !dirs))) return fail(ctx, F3D_ERR_INVALID, "lines_plane_projection: bad arguments");
+    if (n == 0) return F3D_OK;
+    void *ds, *de, *dsp, *dep, *dd;
+    if ((rc = up(ctx, SLOT_XYZ, starts, (size_t)n * 24, &ds)) || (rc = up(ctx, SLOT_OUT1, ends, (size_t)n * 24, &de))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 24, &dsp)) || (rc = ensure(ctx, SLOT_MASKS, (size_t)n * 24, &dep)) ||
+        (rc = ensure(ctx, SLOT_AUX0, (size_t)n * 24, &dd))) return rc;
+    F3D_HIP(ctx, f3d_launch_points_plane_projection((const double*)ds, n, pp, nr, (double*)dsp, ctx->stream));
+    F3D_HIP(ctx, f3d_launch_points_plane_projection((const double*)de, n, pp, nr, (double*)dep, ctx->stream));
+    F3D_HIP(ctx, f3d_launch_unit_difference((const double*)dsp, (const double*)dep, n, (double*)dd, ctx->stream));
+    if ((rc = down(ctx, sp, dsp, (size_t)n * 24)) || (rc = down(ctx, ep, dep, (size_t)n * 24)) || (rc = down(ctx, dirs, dd, (size_t)n * 24))) return rc;
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // (f)#1 same-class connected components
 // ---------------------------------------------------------------------------------------------
 int f3d_components_same_class_dev(f3d_ctx* ctx, const int64_t* classes, int64_t n, const int64_t* offsets, const int32_t* nbrs,

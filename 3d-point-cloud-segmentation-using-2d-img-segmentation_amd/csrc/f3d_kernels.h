@@ -52,6 +52,17 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
 // same-class connected components (f3d_cc.hip): root[i] = smallest index of i's component; parent = int32 [n] scratch
 hipError_t f3d_launch_components(const int64_t* classes, int64_t n, const int64_t* offs, const int32_t* nbrs, int32_t* parent,
                                  int64_t* root, int* err, hipStream_t s);
+// a12: remaining intersections.py primitives (f3d_geom.hip), device pointers
+hipError_t f3d_launch_ray_x_lines(const double o[3], const double d[3], const double* starts, const double* ends, int64_t n, double* pts,
+                                  uint8_t* within, hipStream_t s);
+hipError_t f3d_launch_rays_x_plane(const double pp[3], const double pn[3], const double* origins, const double* dirs, int64_t n, double* pts,
+                                   uint8_t* valid, hipStream_t s);
+hipError_t f3d_launch_lines_x_planes(const double* lo, const double* le, int64_t n, const double* pps, const double* pns, int m, int bmode,
+                                     double* pts, uint8_t* valid, hipStream_t s);
+hipError_t f3d_launch_point_inside_polygon(const double* points, int64_t n, const double* verts, int m, uint8_t* inside, uint8_t* within,
+                                           hipStream_t s);
+hipError_t f3d_launch_points_plane_projection(const double* points, int64_t n, const double pp[3], const double nr[3], double* out, hipStream_t s);
+hipError_t f3d_launch_unit_difference(const double* a, const double* b, int64_t n, double* out, hipStream_t s);
 hipError_t f3d_launch_segment_votes(const double* votes, int64_t npts, int ncols, int nclasses, double threshold,
                                     const f3d_filter_args& flt, int64_t* classes, hipStream_t s);
 hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols,

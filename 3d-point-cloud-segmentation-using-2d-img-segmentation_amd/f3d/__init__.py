@@ -92,6 +92,12 @@ def library():
         'f3d_points_in_obb_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, vp, vp]),
         'f3d_relabel': (i32, [vp, vp, i64, i64, i64, vp]),
         'f3d_relabel_dev': (i32, [vp, vp, i64, i64, i64, vp, vp]),
+        'f3d_ray_x_lines': (i32, [vp, vp, vp, vp, vp, i64, vp, vp]),
+        'f3d_rays_x_plane': (i32, [vp, vp, vp, vp, vp, i64, vp, vp]),
+        'f3d_lines_x_planes': (i32, [vp, vp, vp, i64, vp, vp, i32, vp, vp]),
+        'f3d_point_inside_polygon': (i32, [vp, vp, i64, vp, i32, vp, vp]),
+        'f3d_points_plane_projection': (i32, [vp, vp, i64, vp, vp, vp]),
+        'f3d_lines_plane_projection': (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         'f3d_components_same_class': (i32, [vp, vp, i64, vp, vp, vp]),
         'f3d_components_same_class_dev': (i32, [vp, vp, i64, vp, vp, vp, vp, vp]),
     }
@@ -332,6 +338,50 @@ class Context:
         cnt = np.zeros(1, np.int64)
         self._check(self._lib.f3d_relabel(self._h, _ptr(ids), ids.size, int(from_id), int(to_id), _ptr(cnt)))
         return int(cnt[0])
+
+    # ---- the other intersections.py primitives (a12)
+    @staticmethod
+    def _n3(a):
+        a = _f64(a)
+        if a.ndim != 2 or a.shape[1] != 3:
+            raise ValueError(f'expected [N,3], got {a.shape}')
+        return a
+
+    def ray_x_lines(self, origin, direction, starts, ends):
+        o, d, s, e = _f64(origin, (3,)), _f64(direction, (3,)), self._n3(starts), self._n3(ends)
+        pts, within = np.empty_like(s), np.empty(len(s), np.uint8)
+        self._check(self._lib.f3d_ray_x_lines(self._h, _ptr(o), _ptr(d), _ptr(s), _ptr(e), len(s), _ptr(pts), _ptr(within)))
+        return pts, within.view(np.bool_)
+
+    def rays_x_plane(self, plane_point, plane_normal, origins, directions):
+        pp, pn, o, d = _f64(plane_point, (3,)), _f64(plane_normal, (3,)), self._n3(origins), self._n3(directions)
+        pts, valid = np.empty_like(o), np.empty(len(o), np.uint8)
+        self._check(self._lib.f3d_rays_x_plane(self._h, _ptr(pp), _ptr(pn), _ptr(o), _ptr(d), len(o), _ptr(pts), _ptr(valid)))
+        return pts, valid.view(np.bool_)
+
+    def lines_x_planes(self, line_origins, line_ends, plane_points, plane_normals):
+        lo, le, pp, pn = self._n3(line_origins), self._n3(line_ends), self._n3(plane_points), self._n3(plane_normals)
+        pts, valid = np.empty((len(lo), len(pp), 3)), np.empty((len(lo), len(pp)), np.uint8)
+        self._check(self._lib.f3d_lines_x_planes(self._h, _ptr(lo), _ptr(le), len(lo), _ptr(pp), _ptr(pn), len(pp), _ptr(pts), _ptr(valid)))
+        return pts, valid.view(np.bool_)
+
+    def point_inside_polygon(self, points, vertices):
+        p, v = self._n3(points), self._n3(vertices)
+        inside, within = np.empty(len(p), np.uint8), np.empty((len(v), len(p)), np.uint8)
+        self._check(self._lib.f3d_point_inside_polygon(self._h, _ptr(p), len(p), _ptr(v), len(v), _ptr(inside), _ptr(within)))
+        return inside.view(np.bool_), within.view(np.bool_)
+
+    def points_plane_projection(self, points, plane_point, normal):
+        p, pp, nr = self._n3(points), _f64(plane_point, (3,)), _f64(normal, (3,))
+        out = np.empty_like(p)
+        self._check(self._lib.f3d_points_plane_projection(self._h, _ptr(p), len(p), _ptr(pp), _ptr(nr), _ptr(out)))
+        return out
+
+    def lines_plane_projection(self, starts, ends, plane_point, normal):
+        s, e, pp, nr = self._n3(starts), self._n3(ends), _f64(plane_point, (3,)), _f64(normal, (3,))
+        sp, ep, dr = np.empty_like(s), np.empty_like(s), np.empty_like(s)
+        self._check(self._lib.f3d_lines_plane_projection(self._h, _ptr(s), _ptr(e), len(s), _ptr(pp), _ptr(nr), _ptr(sp), _ptr(ep), _ptr(dr)))
+        return sp, ep, dr
 
     def components_same_class(self, classes, offsets, neighbours):
         """root[i] = smallest index of point i's same-class connected component (CSR adjacency, symmetric)."""

@@ -218,6 +218,29 @@ int f3d_relabel(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
 int f3d_relabel_dev(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
                     int64_t* count_dev, void* stream);
 
+/* ---- a12 / (f)#4: the other primitives of Fusion3DSeg/intersections.py (host pointers) ---- */
+/* ray_x_lines (:6-38): points [n,3], within uint8 [n] */
+int f3d_ray_x_lines(f3d_ctx* ctx, const double origin[3], const double direction[3], const double* starts,
+                    const double* ends, int64_t n, double* points, uint8_t* within);
+/* rays_x_plane (:41-63): points [n,3], valid uint8 [n] */
+int f3d_rays_x_plane(f3d_ctx* ctx, const double plane_point[3], const double plane_normal[3], const double* origins,
+                     const double* directions, int64_t n, double* points, uint8_t* valid);
+/* lines_x_planes (:66-94): points [n,m,3], valid uint8 [n,m].  The reference subtracts [n,3] from [n,m,3] without
+ * a new axis (:89-90): it only broadcasts for n == 1 or n == m (then the segment test uses line m); any other
+ * shape is F3D_ERR_INVALID, where NumPy raises ValueError. */
+int f3d_lines_x_planes(f3d_ctx* ctx, const double* line_origins, const double* line_ends, int64_t n,
+                       const double* plane_points, const double* plane_normals, int m, double* points, uint8_t* valid);
+/* point_inside_polygon (:97-119): inside uint8 [n], within uint8 [m,n] */
+int f3d_point_inside_polygon(f3d_ctx* ctx, const double* points, int64_t n, const double* vertices, int m,
+                             uint8_t* inside, uint8_t* within);
+/* points_plane_projection (:167-180): out [n,3] */
+int f3d_points_plane_projection(f3d_ctx* ctx, const double* points, int64_t n, const double plane_point[3],
+                                const double normal[3], double* out);
+/* lines_plane_projection (:183-204): start / end projections and unit directions, each [n,3] */
+int f3d_lines_plane_projection(f3d_ctx* ctx, const double* starts, const double* ends, int64_t n,
+                               const double plane_point[3], const double normal[3], double* start_proj,
+                               double* end_proj, double* directions);
+
 /* ---- (f)#1: flood fill of split_into_instances (Fusion3DSeg/segUtils/cv.py:425-440) ------ */
 /* Connected components of the adjacency (CSR: offsets int64 [n+1], neighbours int32 [offsets[n]]) restricted to
  * edges whose end points have the same class; root[i] = smallest point index of i's component (= the seed the

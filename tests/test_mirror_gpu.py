@@ -277,3 +277,32 @@ def test_components_kernel_long_chains_and_bad_index():
     nb[5] = n + 3
     with pytest.raises(IndexError):
         ctx.components_same_class(cls, offs, nb)
+
+
+def test_other_intersections_primitives_match_reference_golden(golden):
+    import Fusion3DSeg.intersections as I
+    g = golden('intersections')
+    tol = dict(rtol=1e-11, atol=1e-11)
+    pts, within = I.ray_x_lines(g['rxl_origin'], g['rxl_direction'], g['rxl_starts'], g['rxl_ends'])
+    assert np.allclose(pts, g['rxl_points'], **tol) and np.array_equal(within, g['rxl_within'])
+    pts, valid = I.rays_x_plane(g['rxp_plane_point'], g['rxp_plane_normal'], g['rxp_origins'], g['rxp_directions'])
+    assert np.allclose(pts, g['rxp_points'], **tol) and np.array_equal(valid, g['rxp_valid'])
+    pts, valid = I.lines_x_planes(g['lxp_origins'], g['lxp_ends'], g['lxp_plane_points'], g['lxp_plane_normals'])
+    assert np.allclose(pts, g['lxp_points'], **tol) and np.array_equal(valid, g['lxp_valid'])       # N == M broadcasting quirk
+    assert str(g['lxp_n_ne_m_error']) == 'ValueError'
+    with pytest.raises(ValueError):
+        I.lines_x_planes(np.vstack([g['lxp_origins']] * 2), np.vstack([g['lxp_ends']] * 2), g['lxp_plane_points'], g['lxp_plane_normals'])
+    inside, wb = I.point_inside_polygon(g['pip_points'], g['pip_vertices'])
+    assert np.array_equal(inside, g['pip_inside']) and np.array_equal(wb, g['pip_within'])
+    assert np.allclose(I.plane_x_plane(n1=g['pxp_n1'], n2=g['pxp_n2'], lookat=g['pxp_lookat']), g['pxp_dir_normals'], **tol)
+    assert np.allclose(I.plane_x_plane(v1=g['pxp_v1'], v2=g['pxp_v2']), g['pxp_dir_vertices'], **tol)
+    assert np.allclose(I.points_plane_projection(g['ppp_points'], g['ppp_plane_point'], g['ppp_normal']), g['ppp_out'], **tol)
+    sp, ep, dr = I.lines_plane_projection(g['lpp_starts'], g['lpp_ends'], g['ppp_plane_point'], g['ppp_normal'])
+    assert np.allclose(sp, g['lpp_out0'], **tol) and np.allclose(ep, g['lpp_out1'], **tol) and np.allclose(dr, g['lpp_out2'], **tol)
+    for k in range(len(g['rrc_o1'])):
+        with np.errstate(all='ignore'):
+            pa, pb, dist, hit, wa, wb_ = I.ray_ray_closest(g['rrc_o1'][k], g['rrc_d1'][k], g['rrc_o2'][k], g['rrc_d2'][k])
+        assert np.allclose(pa, g['rrc_pa'][k], equal_nan=True, rtol=1e-9, atol=1e-9)
+        assert np.allclose(pb, g['rrc_pb'][k], equal_nan=True, rtol=1e-9, atol=1e-9)
+        assert np.allclose(dist, g['rrc_distance'][k], equal_nan=True, rtol=1e-9, atol=1e-9)
+        assert [bool(hit), bool(wa), bool(wb_)] == g['rrc_flags'][k].tolist()
