@@ -104,7 +104,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('F3D_BENCH_FORCE_DIST') == '1'     # the env var rehearses the RCCL path on one rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
@@ -124,7 +125,7 @@ def main():
     masks_np = synth.masks(V, S, S, args.masks)
     views = torch.from_numpy(views_np).to(dev)
     masks_full = torch.empty((V, S, S), dtype=torch.uint8, device=dev)
-    if world > 1:
+    if use_dist:
         v0, v1 = sharding.view_bounds(V, rank, world)                # this rank "produced" (owns) the masks of views [v0, v1)
         masks_shard = torch.from_numpy(masks_np[v0:v1]).to(dev)
     else:
@@ -149,18 +150,36 @@ def main():
     else:
         flags |= f3d.FUSE_SORT
 
-    def fuse():
-        ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, masks_full.data_ptr(), S, S,
+    def fuse(masks_t=None):
+        m = masks_full if masks_t is None else masks_t
+        ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, m.data_ptr(), S, S,
                                     133, 0.5, flt, classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
 
+    # N > 1: the mask all-gather of step i+1 (RCCL, its own stream) overlaps the kernels of step i (double-buffered masks).
+    # Issued BEFORE fuse(i): the collective then only waits for fuse(i-1), the last reader of the buffer it overwrites.
+    mask_buf = [masks_full, torch.empty_like(masks_full)] if use_dist else None
+    pending = {}
+    step_no = [0]
+
+    def issue_gather(i):
+        out = mask_buf[i % 2]
+        pending[i] = dist.all_gather_into_tensor(out.view(-1), masks_shard.view(-1), async_op=True)
+
     def step():
-        if world > 1:
-            sharding.all_gather_masks(dist, masks_shard, out=masks_full)     # RCCL over xGMI: the path's one exchange step
-        fuse()
+        if not use_dist:
+            fuse()
+            return
+        i = step_no[0]
+        if i not in pending:
+            issue_gather(i)
+        issue_gather(i + 1)
+        pending.pop(i).wait()                     # the compute stream waits for masks(i); the host does not block
+        fuse(mask_buf[i % 2])
+        step_no[0] = i + 1
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -172,7 +191,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -225,7 +244,7 @@ def main():
                    config=dict(workload=f'C3: {n} points/GPU x {V} ring views, {S}x{S} {args.masks} uint8 masks, '
                                         f'nclasses=133, threshold=0.5, filter_classes={flt}; fused project->sample->vote->segment',
                                points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64', cloud_layout=layout,
-                               exchange='none' if world == 1 else f'RCCL all_gather of {V // world} masks/rank each step'),
+                               exchange='none' if not use_dist else f'RCCL all_gather of {V // world} masks/rank per step, double-buffered and overlapped with the previous step'),
                    roofline=roofline)
 
     # secondary, HBM-streaming kernels of the same path (not part of `value`)
@@ -301,7 +320,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        for w_ in pending.values():
+            w_.wait()
+        torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
 
