@@ -177,9 +177,9 @@ def views_build(K, w, h, wxyzs, translations, max_depth):
 def view_fields(views):
     """Named sub-arrays of a [V,80] view table (for tests and debugging)."""
     v = np.asarray(views)
-    return {'K': v[:, 0:9].reshape(-1, 3, 3), 'qinv': v[:, 9:13], 't': v[:, 13:16],
-            'plane_pt': v[:, 16:31].reshape(-1, 5, 3), 'plane_n': v[:, 31:46].reshape(-1, 5, 3),
-            'M': v[:, 46:55].reshape(-1, 3, 3), 'mnorm': v[:, 55:58]}
+    return {'M': v[:, 0:9].reshape(-1, 3, 3), 't': v[:, 9:12], 'mnorm': v[:, 12:15],
+            'K': v[:, 32:41].reshape(-1, 3, 3), 'qinv': v[:, 41:45],
+            'plane_pt': v[:, 45:60].reshape(-1, 5, 3), 'plane_n': v[:, 60:75].reshape(-1, 5, 3)}
 
 
 def _xyz(points):

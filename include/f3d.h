@@ -66,18 +66,23 @@ typedef enum f3d_dtype {
  *                     bounding box) is accepted/rejected without the exact plane test only when |a|
  *                     exceeds rel32 * (|x|+|y|+|z|) + abs32. */
 typedef struct f3d_view {
-    double K[9];                  /* intrinsics, row-major (camera_utils.py:23)                   */
-    double qinv[4];               /* conj(q)/|q|^2 (w,x,y,z)  (camera_utils.py:22)                */
-    double t[3];                  /* camera translation       (camera_utils.py:21)                */
-    double plane_pt[F3D_NPLANES][3];   /* fusion.py:254-257                                       */
-    double plane_n[F3D_NPLANES][3];    /* inward normals, fusion.py:256-258                       */
+    /* hot (128 B = two scalar-cache lines): everything the fast projection reads */
     double M[9];                  /* K * Rot(qinv), row-major                                     */
+    double t[3];                  /* camera translation       (camera_utils.py:21)                */
     double mnorm[3];              /* ||K row k||_1 * |qinv|^2, rounded up                          */
+    double pad0;
+    /* warm (128 B): float32 planes of the pre-culls */
     float  cull_n32[F3D_NPLANES][3];
     float  cull_off32[F3D_NPLANES];
     float  cull_rel32;
     float  cull_abs32;
-    double reserved[11];
+    float  pad1[10];
+    /* exact data: what the reference's arithmetic uses */
+    double K[9];                  /* intrinsics, row-major (camera_utils.py:23)                   */
+    double qinv[4];               /* conj(q)/|q|^2 (w,x,y,z)  (camera_utils.py:22)                */
+    double plane_pt[F3D_NPLANES][3];   /* fusion.py:254-257                                       */
+    double plane_n[F3D_NPLANES][3];    /* inward normals, fusion.py:256-258                       */
+    double reserved[5];
 } f3d_view;
 
 /* An oriented box as open3d's OrientedBoundingBox exposes it (center, R columns = axes, extent);
