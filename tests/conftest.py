@@ -15,6 +15,10 @@ for p in (str(ROOT), str(PKG)):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run on the GPU box with -m gpu)')
+    # a fresh checkout has no built library (it is git-ignored): build it once (hipcc cross-compiles without a GPU)
+    if not (PKG / 'f3d' / 'libf3d_hip.so').is_file():
+        import subprocess
+        subprocess.run(['make', '-C', str(PKG / 'csrc')], check=True, capture_output=True)
 
 
 @pytest.fixture(scope='session')
