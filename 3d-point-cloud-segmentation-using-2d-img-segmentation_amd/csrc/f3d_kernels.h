@@ -40,7 +40,9 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
 // gather_xyz = true: xyz is the caller's cloud and the kernel reads point perm[i]
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, hipStream_t s);
+                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled, hipStream_t s);
+// masks [V,H,W] row-major -> 8x8-pixel tiles (H, W multiples of 8)
+hipError_t f3d_launch_tile_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, hipStream_t s);
 // audit of the fast projection (tests only): for every (point, view) pair inside the frustum counts
 // stats[0] pairs, stats[1] pairs sent to the exact fallback, stats[2] accepted pairs whose floor differs from the
 // canonical path (must stay 0), stats[3] pairs rejected/accepted by the f32 cull that the exact test contradicts (0)

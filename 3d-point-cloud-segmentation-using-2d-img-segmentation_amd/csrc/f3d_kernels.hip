@@ -128,6 +128,28 @@ __device__ __forceinline__ void cull_point32(const f3d_view& vw, float px, float
     sure = sr & small;
 }
 
+// byte offset of pixel (iu, iv) inside one view's mask: row-major as the caller hands it over, or the 8x8-pixel tiled copy
+// (one 64-B line per tile) made by k_tile_masks -- neighbouring points of a wave then share cache lines in BOTH directions
+__device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W, int tiled) {
+    const unsigned row = (unsigned)(iv * W + iu);
+    const unsigned til = (((unsigned)(iv >> 3) * (unsigned)(W >> 3) + (unsigned)(iu >> 3)) << 6) | ((unsigned)(iv & 7) << 3) | (unsigned)(iu & 7);
+    return tiled ? til : row;
+}
+
+// [V,H,W] row-major -> [V][H/8][W/8][8][8]; one thread moves 8 bytes (one tile row), a wave writes 512 contiguous bytes
+__global__ __launch_bounds__(F3D_BLOCK) void k_tile_masks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int V, int H, int W) {
+    const int64_t per_view = (int64_t)H * W / 8;                    // 8-byte pieces per view
+    const int64_t total = per_view * V;
+    const int tw = W >> 3;
+    for (int64_t k = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; k < total; k += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t v = k / per_view; const int64_t r = k - v * per_view;      // r indexes (tile, row-in-tile) of the destination
+        const int tile = (int)(r >> 3), ry = (int)(r & 7);
+        const int ty = tile / tw, tx = tile - ty * tw;
+        const uint64_t x = *reinterpret_cast<const uint64_t*>(src + (size_t)v * H * W + (size_t)(ty * 8 + ry) * W + tx * 8);
+        *reinterpret_cast<uint64_t*>(dst + (size_t)v * H * W + (size_t)r * 8) = x;
+    }
+}
+
 // fast projection (C).  Returns true when (iu, iv) are proven equal to the canonical floor(u), floor(v) AND lie inside
 // the W x H image; `unsure` is set when the canonical arithmetic has to decide.  umax >= max(W, H): for |u| <= umax
 // the bound is rigorous; beyond it both paths are out of the image anyway.
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                                                      const uint8_t* __restrict__ masks, int H, int W,
                                                      int nclasses, f3d_filter_args flt, double threshold,
                                                      int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
-                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz) {
+                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz, int tiled) {
     using HT = hist_traits<MODE>;
     extern __shared__ uint32_t lds_u32[];
     float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes of one view group
@@ -299,7 +321,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 }
                 vote(pend, pend_label);                     // retire the previous view's vote, then issue this gather
                 pend = hit;
-                pend_label = (masks + (size_t)v * plane)[hit ? (unsigned)(iv * W + iu) : 0u];
+                pend_label = (masks + (size_t)v * plane)[hit ? mask_offset(iu, iv, W, tiled) : 0u];
             }
             // mixed views: per-point float32 cull, exact plane test inside the margin
             todo = valid_m & ~out_m & ~in_m;
@@ -325,7 +347,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 }
                 vote(pend, pend_label);
                 pend = hit;
-                pend_label = (masks + (size_t)v * plane)[hit ? (unsigned)(iv * W + iu) : 0u];
+                pend_label = (masks + (size_t)v * plane)[hit ? mask_offset(iu, iv, W, tiled) : 0u];
             }
         }
         vote(pend, pend_label);
@@ -701,7 +723,7 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
 
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, hipStream_t s) {
+                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);
     const size_t lds = f3d_fuse_lds_bytes(mode, nclasses);
@@ -715,7 +737,7 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_fuse<T, M, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, masks, h, w,  \
-                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0);           \
+                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, tiled ? 1 : 0); \
     } while (0)
 #define F3D_FUSE_T(T)                                                                                          \
     do {                                                                                                       \
@@ -726,6 +748,14 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     if (dtype == F3D_F64) F3D_FUSE_T(double); else F3D_FUSE_T(float);
 #undef F3D_FUSE_T
 #undef F3D_FUSE
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_tile_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, hipStream_t s) {
+    if (nviews <= 0) return hipSuccess;
+    if ((h & 7) || (w & 7) || ((uintptr_t)src & 7) || ((uintptr_t)dst & 7)) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)nviews * h * w / 8;
+    hipLaunchKernelGGL(k_tile_masks, dim3(grid_for(total, F3D_BLOCK, F3D_GRID_CAP)), dim3(F3D_BLOCK), 0, s, src, dst, nviews, h, w);
     return hipGetLastError();
 }
 

@@ -26,6 +26,10 @@
 namespace {
 
 constexpr int SB = 256;
+#ifndef F3D_SORT_BITS
+#define F3D_SORT_BITS 7                      // Morton bits per axis: 2^7 = 128 cubic cells along the longest side
+#endif
+#define F3D_SORT_AXIS (1 << F3D_SORT_BITS)
 
 struct bbox6 { double lo[3], hi[3]; };
 
@@ -86,13 +90,13 @@ __global__ __launch_bounds__(SB) void k_bbox_final(const bbox6* __restrict__ par
         // sorted points is a compact 3-D block (small footprint in every view's mask, good for the per-XCD L2)
         (void)vol; (void)max_cells;
         double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
-        const double cell = emax / 32.0 * 1.0000001;
+        const double cell = emax / (double)F3D_SORT_AXIS * 1.0000001;
         for (int c = 0; c < 3; ++c) {
             int d = (int)(ext[c] / cell) + 1;
-            g.dim[c] = d > 32 ? 32 : d;
+            g.dim[c] = d > F3D_SORT_AXIS ? F3D_SORT_AXIS : d;
         }
         g.inv_cell = 1.0 / cell;
-        g.ncells = 32768;                                      // key space; key 32767 also collects non-finite points
+        g.ncells = 1 << (3 * F3D_SORT_BITS);                   // key space; the last key also collects non-finite points
         *grid = g;
     }
 }
@@ -109,10 +113,10 @@ __device__ __forceinline__ uint32_t cell_of(const T* __restrict__ p, const f3d_c
         k = k < 0 ? 0 : (k >= g.dim[c] ? g.dim[c] - 1 : k);
         idx[c] = k;
     }
-    if (!ok) return 32767u;
+    if (!ok) return (1u << (3 * F3D_SORT_BITS)) - 1u;
     uint32_t key = 0;
 #pragma unroll
-    for (int b = 0; b < 5; ++b)
+    for (int b = 0; b < F3D_SORT_BITS; ++b)
         key |= (((uint32_t)idx[0] >> b) & 1u) << (3 * b + 2) | (((uint32_t)idx[1] >> b) & 1u) << (3 * b + 1) | (((uint32_t)idx[2] >> b) & 1u) << (3 * b);
     return key;
 }
@@ -151,7 +155,7 @@ sort_layout layout_for(int64_t n) {
     L.idx_in = take((size_t)n * 4);
     size_t tb = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (size_t)n, 0u, 16u, (hipStream_t)0);
+                                    (size_t)n, 0u, (unsigned)(3 * F3D_SORT_BITS), (hipStream_t)0);
     L.temp_bytes = tb;
     L.temp = take(tb);
     L.total = off;
@@ -189,7 +193,7 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t tb = L.temp_bytes;
-    e = rocprim::radix_sort_pairs(base + L.temp, tb, keys_in, keys_out, idx_in, reinterpret_cast<uint32_t*>(perm), (size_t)n, 0u, 16u, s);
+    e = rocprim::radix_sort_pairs(base + L.temp, tb, keys_in, keys_out, idx_in, reinterpret_cast<uint32_t*>(perm), (size_t)n, 0u, (unsigned)(3 * F3D_SORT_BITS), s);
     if (e != hipSuccess) return e;
     if (sorted_xyz) {
         if (dtype == F3D_F64) hipLaunchKernelGGL(k_gather_xyz<double>, dim3(gstream), dim3(SB), 0, s, (const double*)xyz, n, perm, (double*)sorted_xyz);

@@ -207,7 +207,7 @@ def test_device_api_sort_flags_and_prepared_layout(ctx):
     views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
     want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
                                  133, 0.5, None)
-    for flags in (0, f3d.FUSE_SORT):
+    for flags in (0, f3d.FUSE_SORT, f3d.FUSE_TILE_MASKS, f3d.FUSE_SORT | f3d.FUSE_TILE_MASKS):
         assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, flags), want), flags
     assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, 0, presort=True), want)
     assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, f3d.FUSE_SORT, f32=True), want)
@@ -299,7 +299,7 @@ def _full_size_case(ctx, name, mask_kind, flt, subset=60_000):
     sc = synth.scene(name, mask_kind=mask_kind)
     pts, n = sc['points'], len(sc['points'])
     views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
-    labels = _dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, f3d.FUSE_SORT)
+    labels = _dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, f3d.FUSE_SORT | f3d.FUSE_TILE_MASKS)
     assert labels.min() >= 0 and labels.max() <= 133
     # (1) the oracle on a random subset agrees with the full run at those indices (labels are per-point functions)
     rng = np.random.default_rng(123)
@@ -339,3 +339,16 @@ def test_config_c1_full_vs_oracle(ctx):
     for thr, flt in [(0.5, None), (0.0, None), (0.5, [86, 114, 115])]:
         want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, thr, flt)
         assert np.array_equal(ctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, thr, flt), want)
+
+
+def test_mask_tiling_falls_back_for_odd_sizes_and_matches(ctx):
+    rng = np.random.default_rng(8)
+    q, t = synth.ring_views(6)
+    pts = synth.cloud(40_000)
+    for (h, w) in [(60, 100), (64, 104), (1, 8)]:                     # 60 is not a multiple of 8 -> row-major path; 64x104 -> tiled
+        K = np.array([[w * 0.8, 0, w / 2], [0, w * 0.8, h / 2], [0, 0, 1]])
+        masks = rng.integers(0, 134, (6, h, w), dtype=np.uint8)
+        views = f3d.views_build(K, w, h, q, t, 10.0)
+        want = O.project_vote_argmax(pts, K, q, t, masks, 10.0, 133, 0.3, None)
+        for flags in (0, f3d.FUSE_TILE_MASKS, f3d.FUSE_TILE_MASKS | f3d.FUSE_SORT):
+            assert np.array_equal(_dev_fuse(ctx, pts, views, masks, None, 0.3, flags), want), (h, w, flags)
