@@ -19,7 +19,7 @@ static_assert(sizeof(f3d_view) == 640, "f3d_view is 80 doubles");
 namespace {
 
 enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_SORT_PERM, SLOT_SORT_SCRATCH,
-       SLOT_TILED_MASKS, SLOT_COUNT };
+       SLOT_TILED_MASKS, SLOT_TODO, SLOT_COUNT };
 
 thread_local char g_create_err[512] = "";
 
@@ -280,7 +280,11 @@ int f3d_views_build(const double K[9], double w, double h, const double* q, cons
             const double off = fma(vw->plane_n[m][0], vw->plane_pt[m][0],
                                fma(vw->plane_n[m][1], vw->plane_pt[m][1], vw->plane_n[m][2] * vw->plane_pt[m][2]));
             vw->cull_off32[m] = (float)off;
+            vw->plane_off[m] = off;
         }
+        // float64 refinement: FMA value and exact value are both within ~12 eps64 * (|p|_1 + |pp|_1) of the real number
+        vw->cull_rel64 = 64.0 * 2.220446049250313e-16 * nmax;
+        vw->cull_abs64 = 64.0 * 2.220446049250313e-16 * l1max + 1e-300;
         vw->cull_rel32 = (float)(eps32 * nmax * 1.0000002);
         vw->cull_abs32 = (float)(eps32 * l1max * 1.0000002 + 1e-30);
         // fast projection operator M = K * Rot(qinv), Rot = the matrix of x -> q x q* for the un-normalised q
@@ -454,8 +458,10 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
         F3D_HIP(ctx, f3d_launch_tile_masks(masks, (uint8_t*)tm, nviews, h, w, s));
         masks = (const uint8_t*)tm; tiled = true;
     }
+    void* todo;                                                                                 // grows on first use only
+    if ((rc = ensure(ctx, SLOT_TODO, 16 + (size_t)n * 4, &todo))) return rc;
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, h, w, nclasses, fa, threshold, classes, votes_u16,
-                                 ctx->dev_err, perm, gather, tiled, s));
+                                 ctx->dev_err, perm, gather, tiled, (unsigned int*)todo, (int32_t*)((char*)todo + 16), s));
     return F3D_OK;
 }
 

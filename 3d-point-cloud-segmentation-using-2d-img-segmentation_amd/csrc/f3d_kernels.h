@@ -37,10 +37,12 @@ hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, co
 size_t f3d_fuse_lds_bytes(int mode, int nclasses);
 int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
 // perm (device, may be NULL): caller-order index of sorted point i.  gather_xyz = false: xyz is already the sorted copy;
-// gather_xyz = true: xyz is the caller's cloud and the kernel reads point perm[i]
+// gather_xyz = true: xyz is the caller's cloud and the kernel reads point perm[i].  todo_count / todo: device scratch
+// (1 counter + n int32) for the points the fast kernel hands to the exact kernel.
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled, hipStream_t s);
+                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled,
+                           unsigned int* todo_count, int32_t* todo, hipStream_t s);
 // masks [V,H,W] row-major -> 8x8-pixel tiles (H, W multiples of 8)
 hipError_t f3d_launch_tile_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, hipStream_t s);
 // audit of the fast projection (tests only): for every (point, view) pair inside the frustum counts

@@ -150,6 +150,20 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_tile_masks(const uint8_t* __restr
     }
 }
 
+// float64 refinement of the point cull (3 FMAs per plane), for the rare lanes inside the float32 margin
+__device__ __forceinline__ void cull_point64(const f3d_view& vw, f3d_p3 p, double pscale, bool& maybe, bool& sure) {
+    const double marg = __builtin_fma(vw.cull_rel64, pscale, vw.cull_abs64);
+    bool mb = true, sr = true;
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        const double a = __builtin_fma(vw.plane_n[m][0], p.x, __builtin_fma(vw.plane_n[m][1], p.y,
+                         __builtin_fma(vw.plane_n[m][2], p.z, -vw.plane_off[m])));
+        mb = mb & (a > -marg);
+        sr = sr & (a > marg);
+    }
+    maybe = mb; sure = sr;
+}
+
 // fast projection (C).  Returns true when (iu, iv) are proven equal to the canonical floor(u), floor(v) AND lie inside
 // the W x H image; `unsure` is set when the canonical arithmetic has to decide.  umax >= max(W, H): for |u| <= umax
 // the bound is rigorous; beyond it both paths are out of the image anyway.
@@ -173,34 +187,104 @@ __device__ __forceinline__ bool project_fast(const f3d_view& vw, f3d_p3 p, int W
     return safe & ((unsigned)iu < (unsigned)W) & ((unsigned)iv < (unsigned)H);
 }
 
-// canonical fallbacks (out-of-line versions raised the kernel's VGPR allocation through the call ABI, so they are inlined)
-__device__ __forceinline__ bool project_exact_cold(const f3d_view* vw, double px, double py, double pz, int W, int H,
-                                                              int* iu, int* iv) {
-    f3d_p3 p; p.x = px; p.y = py; p.z = pz;
-    const f3d_p3 h = f3d_project_h(vw->K, vw->qinv, vw->t, p);
-    const double fu = floor(h.x / h.z), fv = floor(h.y / h.z);
-    const bool in = (fu >= 0.0) & (fu < (double)W) & (fv >= 0.0) & (fv < (double)H);      // NaN compares false
-    *iu = in ? (int)fu : 0; *iv = in ? (int)fv : 0;
-    return in;
-}
-
-__device__ __forceinline__ bool inside_view_cold(const f3d_view* vw, double px, double py, double pz) {
-    f3d_p3 p; p.x = px; p.y = py; p.z = pz;
-    return f3d_inside_view(*vw, p);
-}
-
 __device__ __forceinline__ void project_exact(const f3d_view& vw, f3d_p3 p, double& fu, double& fv) {
     const f3d_p3 h = f3d_project_h(vw.K, vw.qinv, vw.t, p);
     fu = floor(h.x / h.z); fv = floor(h.y / h.z);
 }
 
+// ---- vote state shared by the fast kernel (k_fuse) and the exact kernel (k_fuse_exact)
+template <int MODE>
+struct vote_state {
+    int total = 0, best_c = 0, best_l = 0;
+    int fc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool bad = false;
+};
+
+// branch-free vote: lanes without a sample vote into a spare bin (index ncols) that nothing reads
+template <int MODE>
+__device__ __forceinline__ void vote_add(vote_state<MODE>& st, uint32_t* hist, int tid, const f3d_filter_args& flt, int nclasses,
+                                         bool valid, int label) {
+    using HT = hist_traits<MODE>;
+    st.bad = st.bad | (valid & (label > nclasses));                              // IndexError in the reference (flagged per tile)
+    valid = valid & (label <= nclasses);
+    st.total += valid ? 1 : 0;
+    if (MODE == MODE_FILTER8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st.fc[k] += (valid & (label == flt.cls[k])) ? 1 : 0;
+    } else {
+        const int l = valid ? label : nclasses + 1;
+        const int sh = (l & (HT::per_word - 1)) * HT::bits;
+        const uint32_t old = atomicAdd(&hist[(l >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
+        const int c = (int)((old >> sh) & HT::mask) + 1;
+        const bool better = valid & ((c > st.best_c) | ((c == st.best_c) & (l < st.best_l)));
+        st.best_c = better ? c : st.best_c; st.best_l = better ? l : st.best_l;
+    }
+}
+
+// VotingSegmentation.segment (voting.py:120-135) for one point, then the stores
+template <int MODE, bool WRITE_VOTES>
+__device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const uint32_t* hist, int tid, const f3d_filter_args& flt,
+                                             int nclasses, double threshold, bool store, int64_t orig,
+                                             int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out) {
+    using HT = hist_traits<MODE>;
+    const int ncols = nclasses + 1;
+    int64_t cls;
+    int win_c, win_i;
+    if (MODE == MODE_FILTER8) {
+        win_c = st.fc[0]; win_i = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < flt.nfilter && st.fc[k] > win_c) { win_c = st.fc[k]; win_i = k; }     // first maximum wins
+    } else if (flt.nfilter > 0) {
+        win_c = -1; win_i = 0;
+        for (int k = 0; k < flt.nfilter; ++k) {
+            const int l = filter_at(flt, k);
+            int c = 0;
+            if (l >= 0 && l < ncols) c = (int)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
+            if (c > win_c) { win_c = c; win_i = k; }
+        }
+    } else {
+        win_c = st.best_c; win_i = st.best_l;
+    }
+    if (st.total == 0) cls = nclasses;                                             // :126
+    else {
+        cls = win_i;
+        if ((double)win_c / (double)st.total < threshold) cls = nclasses;          // :128-130
+        if (win_c == 0) cls = nclasses;                                            // :131
+    }
+    if (flt.nfilter > 0) {                                                         // sequential remap (Q3)
+        int64_t r = cls;
+        if (MODE == MODE_FILTER8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k < flt.nfilter && r == k) r = flt.cls[k];
+        } else {
+            for (int k = 0; k < flt.nfilter; ++k) if (r == k) r = filter_at(flt, k);
+        }
+        cls = r;
+    }
+    if (store) classes[orig] = cls;
+    if (WRITE_VOTES && store) {
+        for (int l = 0; l < ncols; ++l)
+            votes_out[(size_t)orig * ncols + l] =
+                (uint16_t)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fuse: the fast kernel.  It contains NO exact arithmetic: a point for which any accelerator cannot prove its
+// decision (a plane within the float32 margin, a pixel within the fast-projection bound of an integer, huge or
+// non-finite coordinates) is not stored; its caller-order index is appended to `todo` and k_fuse_exact, launched
+// right behind, recomputes that point entirely with the reference's arithmetic (about 1e-3 of the points of a
+// random cloud).  Keeping the canonical sequences out of this kernel is what keeps its register budget small.
+// ------------------------------------------------------------------------------------------
 template <typename T, int MODE, bool WRITE_VOTES>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
                                                      const uint8_t* __restrict__ masks, int H, int W,
                                                      int nclasses, f3d_filter_args flt, double threshold,
                                                      int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
-                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz, int tiled) {
+                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz, int tiled,
+                                                     unsigned int* __restrict__ todo_count, int32_t* __restrict__ todo) {
     using HT = hist_traits<MODE>;
     extern __shared__ uint32_t lds_u32[];
     float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes of one view group
@@ -239,6 +323,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
         const float px32 = (float)p.x, py32 = (float)p.y, pz32 = (float)p.z, ps32 = (float)pscale;
         const bool small = pscale < 1.0e30;                // float32 culls are meaningful (no overflow, no NaN)
+        bool defer = live & !small;                        // this point goes to k_fuse_exact
 
         // ---- (A) bounding box of this wave's live, well-behaved points
         float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
@@ -249,8 +334,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
             lo1 = fminf(lo1, __shfl_xor(lo1, off, 64)); hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
             lo2 = fminf(lo2, __shfl_xor(lo2, off, 64)); hi2 = fmaxf(hi2, __shfl_xor(hi2, off, 64));
         }
-        const bool wave_odd = __any(live & !small);        // some lane needs the exact test whatever the box says
-        const bool wave_any = __any(live);
+        const bool wave_any = __any(live & small);
         const float c0 = 0.5f * (lo0 + hi0), c1 = 0.5f * (lo1 + hi1), c2 = 0.5f * (lo2 + hi2);
         const float e0 = 0.5f * (hi0 - lo0) * 1.000002f + 1e-30f, e1 = 0.5f * (hi1 - lo1) * 1.000002f + 1e-30f,
                     e2 = 0.5f * (hi2 - lo2) * 1.000002f + 1e-30f;
@@ -259,30 +343,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         if (MODE != MODE_FILTER8) {
             for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;   // own column only: no barrier
         }
-        int total = 0, best_c = 0, best_l = 0;
-        int fc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        vote_state<MODE> st;
         bool pend = false;                                  // software-pipelined gather: vote one view later
         int pend_label = 0;
-
-        // branch-free vote: lanes without a pending sample vote into a spare bin (index ncols) that nothing reads, so the
-        // view loop is straight-line code (no exec-mask juggling, and the compiler may overlap the next view's loads)
-        bool bad = false;
-        auto vote = [&](bool valid, int label) {
-            bad = bad | (valid & (label > nclasses));                             // IndexError in the reference (flagged per tile)
-            valid = valid & (label <= nclasses);
-            total += valid ? 1 : 0;
-            if (MODE == MODE_FILTER8) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) fc[k] += (valid & (label == flt.cls[k])) ? 1 : 0;
-            } else {
-                const int l = valid ? label : ncols;
-                const int sh = (l & (HT::per_word - 1)) * HT::bits;
-                const uint32_t old = atomicAdd(&hist[(l >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
-                const int c = (int)((old >> sh) & HT::mask) + 1;
-                const bool better = valid & ((c > best_c) | ((c == best_c) & (l < best_l)));
-                best_c = better ? c : best_c; best_l = better ? l : best_l;
-            }
-        };
 
         for (int g = 0; g < ngroups; ++g) {
             if (ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
@@ -301,101 +364,109 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                     box_in = box_in & (base - spread > marg);
                 }
             }
-            unsigned long long valid_m = __ballot(vj < nviews);
+            const unsigned long long valid_m = __ballot(vj < nviews);
             unsigned long long out_m = __ballot(vj < nviews && box_out);
-            unsigned long long in_m = __ballot(vj < nviews && box_in && !box_out);
-            if (wave_odd) { out_m = 0ull; in_m = 0ull; }
-            if (!wave_any) out_m = valid_m;
+            const unsigned long long in_m = __ballot(vj < nviews && box_in && !box_out);
+            if (!wave_any) out_m = valid_m;                 // nothing but deferred / dead lanes in this wave
             // views whose planes all contain the wave's box: every live lane is inside, no cull, no divergence
-            unsigned long long todo = valid_m & ~out_m & in_m;
-            while (todo) {
-                const int bit = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
+            unsigned long long todo_v = valid_m & ~out_m & in_m;
+            while (todo_v) {
+                const int bit = __builtin_ctzll(todo_v);
+                todo_v &= todo_v - 1ull;
                 const int v = 64 * g + bit;
                 const f3d_view& vw = views[v];
                 int iu, iv;
                 bool unsure;
-                bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live;
-                if (__any(unsure & live)) {                 // canonical arithmetic decides
-                    if (unsure & live) hit = project_exact_cold(&vw, p.x, p.y, p.z, W, H, &iu, &iv);
-                }
-                vote(pend, pend_label);                     // retire the previous view's vote, then issue this gather
+                const bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live & small;
+                defer = defer | (unsure & live);
+                vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);    // retire the previous view's vote
                 pend = hit;
                 pend_label = (masks + (size_t)v * plane)[hit ? mask_offset(iu, iv, W, tiled) : 0u];
             }
-            // mixed views: per-point float32 cull, exact plane test inside the margin
-            todo = valid_m & ~out_m & ~in_m;
-            while (todo) {
-                const int bit = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
+            // mixed views: per-point float32 cull; a lane inside the rounding margin of a plane is deferred
+            todo_v = valid_m & ~out_m & ~in_m;
+            while (todo_v) {
+                const int bit = __builtin_ctzll(todo_v);
+                todo_v &= todo_v - 1ull;
                 const int v = 64 * g + bit;
                 const f3d_view& vw = views[v];
                 bool maybe, sure;
                 cull_point32(vw, px32, py32, pz32, ps32, small, maybe, sure);
-                bool inside = live & maybe;
-                if (__any(inside & !sure)) {
-                    if (inside & !sure) inside = inside_view_cold(&vw, p.x, p.y, p.z);
+                bool inside = live & small & sure;
+                const bool unc = live & small & maybe & !sure;
+                if (__any(unc)) {                           // inside the float32 margin: decide with float64 FMAs
+                    if (unc) {
+                        bool m64, s64;
+                        cull_point64(vw, p, pscale, m64, s64);
+                        inside = s64;
+                        defer = defer | (m64 & !s64);       // within rounding of the plane itself: the exact kernel decides
+                    }
                 }
                 bool hit = false;
                 int iu = 0, iv = 0;
                 if (inside) {
                     bool unsure;
                     hit = project_fast(vw, p, W, H, umax, iu, iv, unsure);
-                    if (__any(unsure)) {
-                        if (unsure) hit = project_exact_cold(&vw, p.x, p.y, p.z, W, H, &iu, &iv);
-                    }
+                    defer = defer | unsure;
                 }
-                vote(pend, pend_label);
+                vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);
                 pend = hit;
                 pend_label = (masks + (size_t)v * plane)[hit ? mask_offset(iu, iv, W, tiled) : 0u];
             }
         }
-        vote(pend, pend_label);
-        if (bad) atomicOr(err, F3D_DEVERR_INDEX);
+        vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);
+        if (st.bad & !defer) atomicOr(err, F3D_DEVERR_INDEX);
+        if (defer) todo[atomicAdd(todo_count, 1u)] = (int32_t)(gather_xyz ? orig : i);     // index into xyz as this launch sees it
+        finish_point<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live & !defer, orig, classes, votes_out);
+    }
+}
 
-        // ---- VotingSegmentation.segment (voting.py:120-135) for this point
-        int64_t cls;
-        int win_c, win_i;
-        if (MODE == MODE_FILTER8) {
-            win_c = fc[0]; win_i = 0;
-#pragma unroll
-            for (int k = 1; k < 8; ++k)
-                if (k < flt.nfilter && fc[k] > win_c) { win_c = fc[k]; win_i = k; }     // first maximum wins
-        } else if (flt.nfilter > 0) {
-            win_c = -1; win_i = 0;
-            for (int k = 0; k < flt.nfilter; ++k) {
-                const int l = filter_at(flt, k);
-                int c = 0;
-                if (l >= 0 && l < ncols) c = (int)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
-                if (c > win_c) { win_c = c; win_i = k; }
+// k_fuse_exact: the reference's arithmetic, nothing else, for the points k_fuse deferred (and the whole path of the
+// oracle in kernel form): exact 5-plane test, canonical projection with IEEE divisions, gather, vote, segment.
+template <typename T, int MODE, bool WRITE_VOTES>
+__global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ xyz, const unsigned int* __restrict__ todo_count,
+                                                           const int32_t* __restrict__ todo,
+                                                           const f3d_view* __restrict__ views, int nviews,
+                                                           const uint8_t* __restrict__ masks, int H, int W,
+                                                           int nclasses, f3d_filter_args flt, double threshold,
+                                                           int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
+                                                           int* __restrict__ err, int tiled, const int32_t* __restrict__ perm,
+                                                           int gather_xyz) {
+    using HT = hist_traits<MODE>;
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* hist = lds_u32;
+    const int tid = threadIdx.x;
+    const int ncols = nclasses + 1;
+    const int words = (ncols + 1 + HT::per_word - 1) >> HT::shift;
+    const size_t plane = (size_t)H * (size_t)W;
+    const int64_t count = (int64_t)*todo_count;
+    for (int64_t base = (int64_t)blockIdx.x * F3D_BLOCK; base < count; base += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t k = base + tid;
+        const bool live = k < count;
+        const int64_t src = live ? (int64_t)todo[k] : 0;                          // index into xyz as k_fuse saw it
+        const int64_t orig = (live && perm && !gather_xyz) ? (int64_t)perm[src] : src;
+        f3d_p3 p = {0.0, 0.0, 0.0};
+        if (live) p = load_point(xyz, src);
+        if (MODE != MODE_FILTER8) {
+            for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
+        }
+        vote_state<MODE> st;
+        for (int v = 0; v < nviews; ++v) {
+            const f3d_view& vw = views[v];
+            bool hit = false;
+            unsigned off = 0u;
+            if (live && f3d_inside_view(vw, p)) {
+                double fu, fv;
+                project_exact(vw, p, fu, fv);
+                if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) {   // NaN compares false
+                    hit = true; off = mask_offset((int)fu, (int)fv, W, tiled);
+                }
             }
-        } else {
-            win_c = best_c; win_i = best_l;
+            const int label = hit ? (int)(masks + (size_t)v * plane)[off] : 0;
+            vote_add<MODE>(st, hist, tid, flt, nclasses, hit, label);
         }
-        if (total == 0) cls = nclasses;                                            // :126
-        else {
-            cls = win_i;
-            if ((double)win_c / (double)total < threshold) cls = nclasses;         // :128-130
-            if (win_c == 0) cls = nclasses;                                        // :131
-        }
-        if (flt.nfilter > 0) {                                                     // sequential remap (Q3)
-            if (MODE == MODE_FILTER8) {
-                int64_t r = cls;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) if (k < flt.nfilter && r == k) r = flt.cls[k];
-                cls = r;
-            } else {
-                int64_t r = cls;
-                for (int k = 0; k < flt.nfilter; ++k) if (r == k) r = filter_at(flt, k);
-                cls = r;
-            }
-        }
-        if (live) classes[orig] = cls;
-        if (WRITE_VOTES && live) {
-            for (int l = 0; l < ncols; ++l)
-                votes_out[(size_t)orig * ncols + l] =
-                    (uint16_t)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
-        }
+        if (st.bad) atomicOr(err, F3D_DEVERR_INDEX);
+        finish_point<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live, orig, classes, votes_out);
     }
 }
 
@@ -723,21 +794,29 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
 
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled, hipStream_t s) {
+                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled,
+                           unsigned int* todo_count, int32_t* todo, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);
     const size_t lds = f3d_fuse_lds_bytes(mode, nclasses);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const size_t lds_exact = lds - 64 * F3D_CULL_ROW * sizeof(float);
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
     int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID);
     grid = (grid + 7) & ~7;                                  // the XCD-aware tile mapping needs a multiple of 8 blocks
-    const dim3 g(grid), b(F3D_BLOCK);
+    const dim3 g(grid), b(F3D_BLOCK), ge(512);
+    hipError_t e0 = hipMemsetAsync(todo_count, 0, sizeof(unsigned int), s);
+    if (e0 != hipSuccess) return e0;
 #define F3D_FUSE(T, M, V)                                                                                      \
     do {                                                                                                       \
-        if (lds > 64 * 1024)                                                                                   \
+        if (lds > 64 * 1024) {                                                                                 \
             (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact); \
+        }                                                                                                      \
         hipLaunchKernelGGL((k_fuse<T, M, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, masks, h, w,  \
-                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, tiled ? 1 : 0); \
+                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, tiled ? 1 : 0, todo_count, todo); \
+        hipLaunchKernelGGL((k_fuse_exact<T, M, V>), ge, b, lds_exact, s, (const T*)xyz, todo_count, todo, views_dev, nviews, \
+                           masks, h, w, nclasses, flt, threshold, classes, votes, err, tiled ? 1 : 0, perm, gather_xyz ? 1 : 0); \
     } while (0)
 #define F3D_FUSE_T(T)                                                                                          \
     do {                                                                                                       \

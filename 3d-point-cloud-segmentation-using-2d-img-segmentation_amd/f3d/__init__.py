@@ -179,7 +179,7 @@ def view_fields(views):
     v = np.asarray(views)
     return {'M': v[:, 0:9].reshape(-1, 3, 3), 't': v[:, 9:12], 'mnorm': v[:, 12:15],
             'K': v[:, 32:41].reshape(-1, 3, 3), 'qinv': v[:, 41:45],
-            'plane_pt': v[:, 45:60].reshape(-1, 5, 3), 'plane_n': v[:, 60:75].reshape(-1, 5, 3)}
+            'plane_pt': v[:, 45:60].reshape(-1, 5, 3), 'plane_n': v[:, 60:75].reshape(-1, 5, 3), 'plane_off': v[:, 75:80]}
 
 
 def _xyz(points):

@@ -76,13 +76,15 @@ typedef struct f3d_view {
     float  cull_off32[F3D_NPLANES];
     float  cull_rel32;
     float  cull_abs32;
-    float  pad1[10];
+    double cull_rel64;            /* float64 refinement of the point cull for lanes inside the float32 margin:   */
+    double cull_abs64;            /* a = n . p - plane_off in FMAs; |a| <= rel64 * |p|_1 + abs64 -> exact kernel   */
+    float  pad1[6];
     /* exact data: what the reference's arithmetic uses */
     double K[9];                  /* intrinsics, row-major (camera_utils.py:23)                   */
     double qinv[4];               /* conj(q)/|q|^2 (w,x,y,z)  (camera_utils.py:22)                */
     double plane_pt[F3D_NPLANES][3];   /* fusion.py:254-257                                       */
     double plane_n[F3D_NPLANES][3];    /* inward normals, fusion.py:256-258                       */
-    double reserved[5];
+    double plane_off[F3D_NPLANES];     /* n . plane_pt (only for the float64 cull refinement)      */
 } f3d_view;
 
 /* An oriented box as open3d's OrientedBoundingBox exposes it (center, R columns = axes, extent);
