@@ -108,6 +108,9 @@ template <> struct hist_traits<MODE_HIST8> { static constexpr int per_word = 4, 
 template <> struct hist_traits<MODE_HIST16> { static constexpr int per_word = 2, shift = 1, bits = 16; static constexpr uint32_t mask = 0xFFFFu; };
 template <> struct hist_traits<MODE_FILTER8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
 
+#ifndef F3D_CHUNK
+#define F3D_CHUNK 2                          // all-in views projected per gather batch (3+ pushes the kernel past 128 VGPRs)
+#endif
 #define F3D_CULL_ROW 23                       // floats per view in the LDS cull table (22 used, odd stride = no bank conflicts)
 #define F3D_FAST_EPS 1.1368683772161603e-13   // 2^-43
 
@@ -346,6 +349,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         vote_state<MODE> st;
         bool pend = false;                                  // software-pipelined gather: vote one view later
         int pend_label = 0;
+        bool cpend[F3D_CHUNK]; int clabel[F3D_CHUNK];
+#pragma unroll
+        for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = false; clabel[k] = 0; }
 
         for (int g = 0; g < ngroups; ++g) {
             if (ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
@@ -368,21 +374,35 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
             unsigned long long out_m = __ballot(vj < nviews && box_out);
             const unsigned long long in_m = __ballot(vj < nviews && box_in && !box_out);
             if (!wave_any) out_m = valid_m;                 // nothing but deferred / dead lanes in this wave
-            // views whose planes all contain the wave's box: every live lane is inside, no cull, no divergence
+            // views whose planes all contain the wave's box: every live lane is inside, no cull, no divergence.
+            // Taken F3D_CHUNK at a time: project the chunk, retire the previous chunk's votes, then issue the chunk's mask
+            // gathers back to back -- F3D_CHUNK gathers in flight per wave, each with a whole chunk of arithmetic to land
+            // (in-kernel stamps showed ~90 % of a view iteration waiting for the previous gather with a 1-deep pipeline).
             unsigned long long todo_v = valid_m & ~out_m & in_m;
             while (todo_v) {
-                const int bit = __builtin_ctzll(todo_v);
-                todo_v &= todo_v - 1ull;
-                const int v = 64 * g + bit;
-                const f3d_view& vw = views[v];
-                int iu, iv;
-                bool unsure;
-                const bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live & small;
-                defer = defer | (unsure & live);
-                vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);    // retire the previous view's vote
-                pend = hit;
-                pend_label = (masks + (size_t)v * plane)[hit ? mask_offset(iu, iv, W, tiled) : 0u];
+                int cv[F3D_CHUNK]; unsigned coff[F3D_CHUNK]; bool chit[F3D_CHUNK];
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) {
+                    cv[k] = 0; coff[k] = 0u; chit[k] = false;
+                    if (todo_v) {
+                        const int bit = __builtin_ctzll(todo_v);
+                        todo_v &= todo_v - 1ull;
+                        const int v = 64 * g + bit;
+                        const f3d_view& vw = views[v];
+                        int iu, iv;
+                        bool unsure;
+                        const bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live & small;
+                        defer = defer | (unsure & live);
+                        cv[k] = v; chit[k] = hit; coff[k] = hit ? mask_offset(iu, iv, W, tiled) : 0u;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k], clabel[k]);
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = chit[k]; clabel[k] = (masks + (size_t)cv[k] * plane)[coff[k]]; }
             }
+#pragma unroll
+            for (int k = 0; k < F3D_CHUNK; ++k) { vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k], clabel[k]); cpend[k] = false; }
             // mixed views: per-point float32 cull; a lane inside the rounding margin of a plane is deferred
             todo_v = valid_m & ~out_m & ~in_m;
             while (todo_v) {
