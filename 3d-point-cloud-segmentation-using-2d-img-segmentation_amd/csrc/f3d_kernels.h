@@ -11,9 +11,10 @@
 
 struct f3d_cellgrid {                      // device-resident description of the cell-sort grid
     double lo[3];
-    double inv_cell;
-    int dim[3];
-    int ncells;                            // dim[0]*dim[1]*dim[2] + 1 (last cell: non-finite points)
+    double inv_cell[3];
+    int dim[3];                            // cells per axis = 1 << bits[c]
+    int bits[3];                           // key bits given to each axis
+    int ncells;                            // key space (last key: non-finite points)
 };
 
 struct f3d_plane_args {                    // by-value kernel argument of k_inside_polyhedra

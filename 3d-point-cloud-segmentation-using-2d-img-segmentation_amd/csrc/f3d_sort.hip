@@ -26,10 +26,9 @@
 namespace {
 
 constexpr int SB = 256;
-#ifndef F3D_SORT_BITS
-#define F3D_SORT_BITS 7                      // Morton bits per axis: 2^7 = 128 cubic cells along the longest side
+#ifndef F3D_SORT_KEY_BITS
+#define F3D_SORT_KEY_BITS 16                 // total key bits = radix passes x 8
 #endif
-#define F3D_SORT_AXIS (1 << F3D_SORT_BITS)
 
 struct bbox6 { double lo[3], hi[3]; };
 
@@ -86,17 +85,27 @@ __global__ __launch_bounds__(SB) void k_bbox_final(const bbox6* __restrict__ par
             if (!(ext[c] > 1e-12)) ext[c] = 1e-12;
             vol *= ext[c];
         }
-        // cubic cells, at most 32 per axis: the key is the 15-bit Morton code of (ix, iy, iz), so a contiguous run of
-        // sorted points is a compact 3-D block (small footprint in every view's mask, good for the per-XCD L2)
+        // F3D_SORT_KEY_BITS key bits are dealt to the axes one at a time, always to the axis whose cells are currently the
+        // longest, so the cells come out as cubic as the box allows; the key interleaves the axes' bits from the most
+        // significant level down (a Morton code with per-axis bit counts), so a contiguous run of sorted points is a
+        // compact 3-D block (small footprint in every view's mask, good for gather coalescing and the per-XCD L2).
         (void)vol; (void)max_cells;
-        double emax = ext[0] > ext[1] ? (ext[0] > ext[2] ? ext[0] : ext[2]) : (ext[1] > ext[2] ? ext[1] : ext[2]);
-        const double cell = emax / (double)F3D_SORT_AXIS * 1.0000001;
-        for (int c = 0; c < 3; ++c) {
-            int d = (int)(ext[c] / cell) + 1;
-            g.dim[c] = d > F3D_SORT_AXIS ? F3D_SORT_AXIS : d;
+        int bits[3] = {0, 0, 0};
+        for (int k = 0; k < F3D_SORT_KEY_BITS; ++k) {
+            int best = 0;
+            double bl = -1.0;
+            for (int c = 0; c < 3; ++c) {
+                const double len = ext[c] / (double)(1 << bits[c]);
+                if (len > bl) { bl = len; best = c; }
+            }
+            ++bits[best];
         }
-        g.inv_cell = 1.0 / cell;
-        g.ncells = 1 << (3 * F3D_SORT_BITS);                   // key space; the last key also collects non-finite points
+        for (int c = 0; c < 3; ++c) {
+            g.dim[c] = 1 << bits[c];
+            g.bits[c] = bits[c];
+            g.inv_cell[c] = (double)g.dim[c] / (ext[c] * 1.0000001);
+        }
+        g.ncells = 1 << F3D_SORT_KEY_BITS;                     // key space; the last key also collects non-finite points
         *grid = g;
     }
 }
@@ -109,15 +118,16 @@ __device__ __forceinline__ uint32_t cell_of(const T* __restrict__ p, const f3d_c
     for (int c = 0; c < 3; ++c) {
         const double x = (double)p[c];
         ok = ok && (fabs(x) < 1e300);
-        int k = (int)((x - g.lo[c]) * g.inv_cell);
+        int k = (int)((x - g.lo[c]) * g.inv_cell[c]);
         k = k < 0 ? 0 : (k >= g.dim[c] ? g.dim[c] - 1 : k);
         idx[c] = k;
     }
-    if (!ok) return (1u << (3 * F3D_SORT_BITS)) - 1u;
+    if (!ok) return (1u << F3D_SORT_KEY_BITS) - 1u;
     uint32_t key = 0;
+    for (int level = F3D_SORT_KEY_BITS - 1; level >= 0; --level)     // at most 3 bits appended per level
 #pragma unroll
-    for (int b = 0; b < F3D_SORT_BITS; ++b)
-        key |= (((uint32_t)idx[0] >> b) & 1u) << (3 * b + 2) | (((uint32_t)idx[1] >> b) & 1u) << (3 * b + 1) | (((uint32_t)idx[2] >> b) & 1u) << (3 * b);
+        for (int c = 0; c < 3; ++c)
+            if (g.bits[c] > level) key = (key << 1) | (((uint32_t)idx[c] >> level) & 1u);
     return key;
 }
 
@@ -148,14 +158,14 @@ sort_layout layout_for(int64_t n) {
     sort_layout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
-    L.grid = take(64);
+    L.grid = take(sizeof(f3d_cellgrid));
     L.partial = take(1024 * sizeof(bbox6));
     L.keys_in = take((size_t)n * 4);
     L.keys_out = take((size_t)n * 4);
     L.idx_in = take((size_t)n * 4);
     size_t tb = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (size_t)n, 0u, (unsigned)(3 * F3D_SORT_BITS), (hipStream_t)0);
+                                    (size_t)n, 0u, (unsigned)F3D_SORT_KEY_BITS, (hipStream_t)0);
     L.temp_bytes = tb;
     L.temp = take(tb);
     L.total = off;
@@ -193,7 +203,7 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t tb = L.temp_bytes;
-    e = rocprim::radix_sort_pairs(base + L.temp, tb, keys_in, keys_out, idx_in, reinterpret_cast<uint32_t*>(perm), (size_t)n, 0u, (unsigned)(3 * F3D_SORT_BITS), s);
+    e = rocprim::radix_sort_pairs(base + L.temp, tb, keys_in, keys_out, idx_in, reinterpret_cast<uint32_t*>(perm), (size_t)n, 0u, (unsigned)F3D_SORT_KEY_BITS, s);
     if (e != hipSuccess) return e;
     if (sorted_xyz) {
         if (dtype == F3D_F64) hipLaunchKernelGGL(k_gather_xyz<double>, dim3(gstream), dim3(SB), 0, s, (const double*)xyz, n, perm, (double*)sorted_xyz);
