@@ -29,6 +29,11 @@ constexpr int SB = 256;
 #ifndef F3D_SORT_KEY_BITS
 #define F3D_SORT_KEY_BITS 16                 // total key bits = radix passes x 8
 #endif
+#if F3D_SORT_KEY_BITS <= 16
+typedef uint16_t sort_key_t;                 // 2-byte keys: the radix passes move 6 B per point instead of 8
+#else
+typedef uint32_t sort_key_t;
+#endif
 
 struct bbox6 { double lo[3], hi[3]; };
 
@@ -133,10 +138,10 @@ __device__ __forceinline__ uint32_t cell_of(const T* __restrict__ p, const f3d_c
 
 template <typename T>
 __global__ __launch_bounds__(SB) void k_cell_keys(const T* __restrict__ xyz, int64_t n, const f3d_cellgrid* __restrict__ grid,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                                                   sort_key_t* __restrict__ keys, uint32_t* __restrict__ idx) {
     const f3d_cellgrid g = *grid;
     for (int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x; i < n; i += (int64_t)gridDim.x * SB) {
-        keys[i] = cell_of(xyz + 3 * i, g);
+        keys[i] = (sort_key_t)cell_of(xyz + 3 * i, g);
         idx[i] = (uint32_t)i;
     }
 }
@@ -160,11 +165,11 @@ sort_layout layout_for(int64_t n) {
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     L.grid = take(sizeof(f3d_cellgrid));
     L.partial = take(1024 * sizeof(bbox6));
-    L.keys_in = take((size_t)n * 4);
-    L.keys_out = take((size_t)n * 4);
+    L.keys_in = take((size_t)n * sizeof(sort_key_t));
+    L.keys_out = take((size_t)n * sizeof(sort_key_t));
     L.idx_in = take((size_t)n * 4);
     size_t tb = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+    (void)rocprim::radix_sort_pairs(nullptr, tb, (sort_key_t*)nullptr, (sort_key_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                     (size_t)n, 0u, (unsigned)F3D_SORT_KEY_BITS, (hipStream_t)0);
     L.temp_bytes = tb;
     L.temp = take(tb);
@@ -183,8 +188,8 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     char* base = reinterpret_cast<char*>(scratch);
     f3d_cellgrid* grid = reinterpret_cast<f3d_cellgrid*>(base + L.grid);
     bbox6* partial = reinterpret_cast<bbox6*>(base + L.partial);
-    uint32_t* keys_in = reinterpret_cast<uint32_t*>(base + L.keys_in);
-    uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + L.keys_out);
+    sort_key_t* keys_in = reinterpret_cast<sort_key_t*>(base + L.keys_in);
+    sort_key_t* keys_out = reinterpret_cast<sort_key_t*>(base + L.keys_out);
     uint32_t* idx_in = reinterpret_cast<uint32_t*>(base + L.idx_in);
     const int64_t gb = (n + SB - 1) / SB;
     const int64_t stride = n > (1 << 18) ? n >> 18 : 1;          // inspect <= ~262k points for the bounding box
