@@ -95,7 +95,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_inside_polyhedra(const T* __restr
 // argmax (count desc, label asc = first-maximum rule of np.argmax), or to 8 register counters when
 // filter_classes has <= 8 entries.
 // ------------------------------------------------------------------------------------------
-enum { MODE_HIST8 = 0, MODE_HIST16 = 1, MODE_FILTER8 = 2 };
+enum { MODE_HIST8 = 0, MODE_HIST16 = 1 };
 
 // k-th entry of filter_classes: short lists travel in the kernarg, long ones in device memory
 __device__ __forceinline__ int filter_at(const f3d_filter_args& flt, int k) {
@@ -106,7 +106,6 @@ template <int MODE>
 struct hist_traits;
 template <> struct hist_traits<MODE_HIST8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
 template <> struct hist_traits<MODE_HIST16> { static constexpr int per_word = 2, shift = 1, bits = 16; static constexpr uint32_t mask = 0xFFFFu; };
-template <> struct hist_traits<MODE_FILTER8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
 
 #ifndef F3D_CHUNK
 #define F3D_CHUNK 2                          // all-in views projected per gather batch (3+ pushes the kernel past 128 VGPRs)
@@ -199,7 +198,6 @@ __device__ __forceinline__ void project_exact(const f3d_view& vw, f3d_p3 p, doub
 template <int MODE>
 struct vote_state {
     int total = 0, best_c = 0, best_l = 0;
-    int fc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool bad = false;
 };
 
@@ -211,17 +209,12 @@ __device__ __forceinline__ void vote_add(vote_state<MODE>& st, uint32_t* hist, i
     st.bad = st.bad | (valid & (label > nclasses));                              // IndexError in the reference (flagged per tile)
     valid = valid & (label <= nclasses);
     st.total += valid ? 1 : 0;
-    if (MODE == MODE_FILTER8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) st.fc[k] += (valid & (label == flt.cls[k])) ? 1 : 0;
-    } else {
-        const int l = valid ? label : nclasses + 1;
-        const int sh = (l & (HT::per_word - 1)) * HT::bits;
-        const uint32_t old = atomicAdd(&hist[(l >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
-        const int c = (int)((old >> sh) & HT::mask) + 1;
-        const bool better = valid & ((c > st.best_c) | ((c == st.best_c) & (l < st.best_l)));
-        st.best_c = better ? c : st.best_c; st.best_l = better ? l : st.best_l;
-    }
+    const int l = valid ? label : nclasses + 1;
+    const int sh = (l & (HT::per_word - 1)) * HT::bits;
+    const uint32_t old = atomicAdd(&hist[(l >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
+    const int c = (int)((old >> sh) & HT::mask) + 1;
+    const bool better = valid & ((c > st.best_c) | ((c == st.best_c) & (l < st.best_l)));
+    st.best_c = better ? c : st.best_c; st.best_l = better ? l : st.best_l;
 }
 
 // VotingSegmentation.segment (voting.py:120-135) for one point, then the stores
@@ -233,12 +226,7 @@ __device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const u
     const int ncols = nclasses + 1;
     int64_t cls;
     int win_c, win_i;
-    if (MODE == MODE_FILTER8) {
-        win_c = st.fc[0]; win_i = 0;
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            if (k < flt.nfilter && st.fc[k] > win_c) { win_c = st.fc[k]; win_i = k; }     // first maximum wins
-    } else if (flt.nfilter > 0) {
+    if (flt.nfilter > 0) {                                                       // votes[:, filter_classes]: first maximum wins
         win_c = -1; win_i = 0;
         for (int k = 0; k < flt.nfilter; ++k) {
             const int l = filter_at(flt, k);
@@ -257,12 +245,7 @@ __device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const u
     }
     if (flt.nfilter > 0) {                                                         // sequential remap (Q3)
         int64_t r = cls;
-        if (MODE == MODE_FILTER8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if (k < flt.nfilter && r == k) r = flt.cls[k];
-        } else {
-            for (int k = 0; k < flt.nfilter; ++k) if (r == k) r = filter_at(flt, k);
-        }
+        for (int k = 0; k < flt.nfilter; ++k) if (r == k) r = filter_at(flt, k);
         cls = r;
     }
     if (store) classes[orig] = cls;
@@ -343,9 +326,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                     e2 = 0.5f * (hi2 - lo2) * 1.000002f + 1e-30f;
         const float ps_box = ((fabsf(c0) + fabsf(c1)) + fabsf(c2)) + ((e0 + e1) + e2);
 
-        if (MODE != MODE_FILTER8) {
-            for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;   // own column only: no barrier
-        }
+        for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;       // own column only: no barrier
         vote_state<MODE> st;
         bool pend = false;                                  // software-pipelined gather: vote one view later
         int pend_label = 0;
@@ -467,9 +448,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ 
         const int64_t orig = (live && perm && !gather_xyz) ? (int64_t)perm[src] : src;
         f3d_p3 p = {0.0, 0.0, 0.0};
         if (live) p = load_point(xyz, src);
-        if (MODE != MODE_FILTER8) {
-            for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
-        }
+        for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
         vote_state<MODE> st;
         for (int v = 0; v < nviews; ++v) {
             const f3d_view& vw = views[v];
@@ -799,16 +778,15 @@ hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, co
 
 size_t f3d_fuse_lds_bytes(int mode, int nclasses) {
     const int ncols = nclasses + 1;
-    size_t hist = 0;
-    if (mode != MODE_FILTER8) {
-        const int per_word = (mode == MODE_HIST8) ? 4 : 2;
-        hist = (size_t)((ncols + 1 + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);   // + the spare bin
-    }
+    const int per_word = (mode == MODE_HIST8) ? 4 : 2;
+    const size_t hist = (size_t)((ncols + 1 + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);   // + the spare bin
     return 64 * F3D_CULL_ROW * sizeof(float) + hist;
 }
 
 int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
-    if (nfilter > 0 && nfilter <= 8 && !want_votes) return MODE_FILTER8;
+    // (a register-counter mode for <= 8 filter classes was tried: it needs more VGPRs than the LDS histogram, drops the kernel
+    // to 3 waves per SIMD and measured 1.74 ms against 1.52 ms per C3 step)
+    (void)nfilter; (void)want_votes;
     return nviews <= 255 ? MODE_HIST8 : MODE_HIST16;
 }
 
@@ -840,8 +818,7 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     } while (0)
 #define F3D_FUSE_T(T)                                                                                          \
     do {                                                                                                       \
-        if (mode == MODE_FILTER8) F3D_FUSE(T, MODE_FILTER8, false);                                            \
-        else if (mode == MODE_HIST8) { if (votes) F3D_FUSE(T, MODE_HIST8, true); else F3D_FUSE(T, MODE_HIST8, false); } \
+        if (mode == MODE_HIST8) { if (votes) F3D_FUSE(T, MODE_HIST8, true); else F3D_FUSE(T, MODE_HIST8, false); } \
         else { if (votes) F3D_FUSE(T, MODE_HIST16, true); else F3D_FUSE(T, MODE_HIST16, false); }              \
     } while (0)
     if (dtype == F3D_F64) F3D_FUSE_T(double); else F3D_FUSE_T(float);
