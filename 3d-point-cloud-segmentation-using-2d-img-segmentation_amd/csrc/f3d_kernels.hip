@@ -132,10 +132,10 @@ __device__ __forceinline__ void cull_point32(const f3d_view& vw, float px, float
 
 // byte offset of pixel (iu, iv) inside one view's mask: row-major as the caller hands it over, or the 8x8-pixel tiled copy
 // (one 64-B line per tile) made by k_tile_masks -- neighbouring points of a wave then share cache lines in BOTH directions
-__device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W, int tiled) {
-    const unsigned row = (unsigned)(iv * W + iu);
-    const unsigned til = (((unsigned)(iv >> 3) * (unsigned)(W >> 3) + (unsigned)(iu >> 3)) << 6) | ((unsigned)(iv & 7) << 3) | (unsigned)(iu & 7);
-    return tiled ? til : row;
+template <bool TILED>
+__device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W) {
+    if (TILED) return (((unsigned)(iv >> 3) * (unsigned)(W >> 3) + (unsigned)(iu >> 3)) << 6) | ((unsigned)(iv & 7) << 3) | (unsigned)(iu & 7);
+    return (unsigned)(iv * W + iu);
 }
 
 // [V,H,W] row-major -> [V][H/8][W/8][8][8]; one thread moves 8 bytes (one tile row), a wave writes 512 contiguous bytes
@@ -197,7 +197,8 @@ __device__ __forceinline__ void project_exact(const f3d_view& vw, f3d_p3 p, doub
 // ---- vote state shared by the fast kernel (k_fuse) and the exact kernel (k_fuse_exact)
 template <int MODE>
 struct vote_state {
-    int total = 0, best_c = 0, best_l = 0;
+    int total = 0;
+    unsigned best = 0;                   // (count << 16) | (0xFFFF - label): the maximum is the highest count, then the lowest label
     bool bad = false;
 };
 
@@ -209,12 +210,12 @@ __device__ __forceinline__ void vote_add(vote_state<MODE>& st, uint32_t* hist, i
     st.bad = st.bad | (valid & (label > nclasses));                              // IndexError in the reference (flagged per tile)
     valid = valid & (label <= nclasses);
     st.total += valid ? 1 : 0;
-    const int l = valid ? label : nclasses + 1;
-    const int sh = (l & (HT::per_word - 1)) * HT::bits;
+    const unsigned l = valid ? (unsigned)label : (unsigned)nclasses + 1u;
+    const unsigned sh = (l & (HT::per_word - 1)) * HT::bits;
     const uint32_t old = atomicAdd(&hist[(l >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
-    const int c = (int)((old >> sh) & HT::mask) + 1;
-    const bool better = valid & ((c > st.best_c) | ((c == st.best_c) & (l < st.best_l)));
-    st.best_c = better ? c : st.best_c; st.best_l = better ? l : st.best_l;
+    const unsigned c = ((old >> sh) & HT::mask) + 1u;
+    const unsigned key = valid ? ((c << 16) | (0xFFFFu - l)) : 0u;
+    st.best = st.best > key ? st.best : key;
 }
 
 // VotingSegmentation.segment (voting.py:120-135) for one point, then the stores
@@ -235,7 +236,7 @@ __device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const u
             if (c > win_c) { win_c = c; win_i = k; }
         }
     } else {
-        win_c = st.best_c; win_i = st.best_l;
+        win_c = (int)(st.best >> 16); win_i = (int)(0xFFFFu - (st.best & 0xFFFFu));
     }
     if (st.total == 0) cls = nclasses;                                             // :126
     else {
@@ -263,13 +264,13 @@ __device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const u
 // right behind, recomputes that point entirely with the reference's arithmetic (about 1e-3 of the points of a
 // random cloud).  Keeping the canonical sequences out of this kernel is what keeps its register budget small.
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE, bool WRITE_VOTES>
+template <typename T, int MODE, bool WRITE_VOTES, bool TILED>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
                                                      const uint8_t* __restrict__ masks, int H, int W,
                                                      int nclasses, f3d_filter_args flt, double threshold,
                                                      int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
-                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz, int tiled,
+                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
                                                      unsigned int* __restrict__ todo_count, int32_t* __restrict__ todo) {
     using HT = hist_traits<MODE>;
     extern __shared__ uint32_t lds_u32[];
@@ -330,9 +331,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         vote_state<MODE> st;
         bool pend = false;                                  // software-pipelined gather: vote one view later
         int pend_label = 0;
-        bool cpend[F3D_CHUNK]; int clabel[F3D_CHUNK];
+        int cpend[F3D_CHUNK], clabel[F3D_CHUNK];
 #pragma unroll
-        for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = false; clabel[k] = 0; }
+        for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = -1; clabel[k] = 0; }
 
         for (int g = 0; g < ngroups; ++g) {
             if (ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
@@ -361,10 +362,10 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
             // (in-kernel stamps showed ~90 % of a view iteration waiting for the previous gather with a 1-deep pipeline).
             unsigned long long todo_v = valid_m & ~out_m & in_m;
             while (todo_v) {
-                int cv[F3D_CHUNK]; unsigned coff[F3D_CHUNK]; bool chit[F3D_CHUNK];
+                int cv[F3D_CHUNK], coff[F3D_CHUNK];          // coff < 0: no sample (validity travels as the sign bit, not as a bool)
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) {
-                    cv[k] = 0; coff[k] = 0u; chit[k] = false;
+                    cv[k] = 0; coff[k] = -1;
                     if (todo_v) {
                         const int bit = __builtin_ctzll(todo_v);
                         todo_v &= todo_v - 1ull;
@@ -374,16 +375,16 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                         bool unsure;
                         const bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live & small;
                         defer = defer | (unsure & live);
-                        cv[k] = v; chit[k] = hit; coff[k] = hit ? mask_offset(iu, iv, W, tiled) : 0u;
+                        cv[k] = v; coff[k] = hit ? (int)mask_offset<TILED>(iu, iv, W) : -1;
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < F3D_CHUNK; ++k) vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k], clabel[k]);
+                for (int k = 0; k < F3D_CHUNK; ++k) vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k] >= 0, clabel[k]);
 #pragma unroll
-                for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = chit[k]; clabel[k] = (masks + (size_t)cv[k] * plane)[coff[k]]; }
+                for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = coff[k]; clabel[k] = (masks + (size_t)cv[k] * plane)[max(coff[k], 0)]; }
             }
 #pragma unroll
-            for (int k = 0; k < F3D_CHUNK; ++k) { vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k], clabel[k]); cpend[k] = false; }
+            for (int k = 0; k < F3D_CHUNK; ++k) { vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k] >= 0, clabel[k]); cpend[k] = -1; }
             // mixed views: per-point float32 cull; a lane inside the rounding margin of a plane is deferred
             todo_v = valid_m & ~out_m & ~in_m;
             while (todo_v) {
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 }
                 vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);
                 pend = hit;
-                pend_label = (masks + (size_t)v * plane)[hit ? mask_offset(iu, iv, W, tiled) : 0u];
+                pend_label = (masks + (size_t)v * plane)[hit ? mask_offset<TILED>(iu, iv, W) : 0u];
             }
         }
         vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);
@@ -424,14 +425,14 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
 
 // k_fuse_exact: the reference's arithmetic, nothing else, for the points k_fuse deferred (and the whole path of the
 // oracle in kernel form): exact 5-plane test, canonical projection with IEEE divisions, gather, vote, segment.
-template <typename T, int MODE, bool WRITE_VOTES>
+template <typename T, int MODE, bool WRITE_VOTES, bool TILED>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ xyz, const unsigned int* __restrict__ todo_count,
                                                            const int32_t* __restrict__ todo,
                                                            const f3d_view* __restrict__ views, int nviews,
                                                            const uint8_t* __restrict__ masks, int H, int W,
                                                            int nclasses, f3d_filter_args flt, double threshold,
                                                            int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
-                                                           int* __restrict__ err, int tiled, const int32_t* __restrict__ perm,
+                                                           int* __restrict__ err, const int32_t* __restrict__ perm,
                                                            int gather_xyz) {
     using HT = hist_traits<MODE>;
     extern __shared__ uint32_t lds_u32[];
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ 
                 double fu, fv;
                 project_exact(vw, p, fu, fv);
                 if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) {   // NaN compares false
-                    hit = true; off = mask_offset((int)fu, (int)fv, W, tiled);
+                    hit = true; off = mask_offset<TILED>((int)fu, (int)fv, W);
                 }
             }
             const int label = hit ? (int)(masks + (size_t)v * plane)[off] : 0;
@@ -805,17 +806,18 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     const dim3 g(grid), b(F3D_BLOCK), ge(512);
     hipError_t e0 = hipMemsetAsync(todo_count, 0, sizeof(unsigned int), s);
     if (e0 != hipSuccess) return e0;
-#define F3D_FUSE(T, M, V)                                                                                      \
+#define F3D_FUSE2(T, M, V, TL)                                                                                 \
     do {                                                                                                       \
         if (lds > 64 * 1024) {                                                                                 \
-            (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            (void)hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact); \
+            (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact); \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_fuse<T, M, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, masks, h, w,  \
-                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, tiled ? 1 : 0, todo_count, todo); \
-        hipLaunchKernelGGL((k_fuse_exact<T, M, V>), ge, b, lds_exact, s, (const T*)xyz, todo_count, todo, views_dev, nviews, \
-                           masks, h, w, nclasses, flt, threshold, classes, votes, err, tiled ? 1 : 0, perm, gather_xyz ? 1 : 0); \
+        hipLaunchKernelGGL((k_fuse<T, M, V, TL>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, masks, h, w, \
+                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo); \
+        hipLaunchKernelGGL((k_fuse_exact<T, M, V, TL>), ge, b, lds_exact, s, (const T*)xyz, todo_count, todo, views_dev, nviews, \
+                           masks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0); \
     } while (0)
+#define F3D_FUSE(T, M, V) do { if (tiled) F3D_FUSE2(T, M, V, true); else F3D_FUSE2(T, M, V, false); } while (0)
 #define F3D_FUSE_T(T)                                                                                          \
     do {                                                                                                       \
         if (mode == MODE_HIST8) { if (votes) F3D_FUSE(T, MODE_HIST8, true); else F3D_FUSE(T, MODE_HIST8, false); } \
@@ -824,6 +826,7 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     if (dtype == F3D_F64) F3D_FUSE_T(double); else F3D_FUSE_T(float);
 #undef F3D_FUSE_T
 #undef F3D_FUSE
+#undef F3D_FUSE2
     return hipGetLastError();
 }
 
