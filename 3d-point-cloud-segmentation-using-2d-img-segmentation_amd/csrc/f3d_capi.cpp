@@ -451,17 +451,17 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
         F3D_HIP(ctx, f3d_launch_cell_sort(xyz, dtype, n, nullptr, (int32_t*)sperm, scratch, s));
         perm = (const int32_t*)sperm; gather = true;                                            // the kernel reads xyz[perm[i]]
     }
-    bool tiled = false;
-    if ((flags & F3D_FUSE_TILE_MASKS) && nviews > 0 && !(h & 7) && !(w & 7) && !((uintptr_t)masks & 7)) {
+    const uint8_t* cmasks = nullptr;                                                            // coded, tiled copy for the fast kernel
+    if (nviews > 0 && nclasses <= F3D_CODE_MAX_NCLASSES) {
         void* tm;                                                                               // grows on first use only
-        if ((rc = ensure(ctx, SLOT_TILED_MASKS, (size_t)nviews * h * w, &tm))) return rc;
-        F3D_HIP(ctx, f3d_launch_tile_masks(masks, (uint8_t*)tm, nviews, h, w, s));
-        masks = (const uint8_t*)tm; tiled = true;
+        if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &tm))) return rc;
+        F3D_HIP(ctx, f3d_launch_code_masks(masks, (uint8_t*)tm, nviews, h, w, nclasses, s));
+        cmasks = (const uint8_t*)tm;
     }
     void* todo;                                                                                 // grows on first use only
     if ((rc = ensure(ctx, SLOT_TODO, 16 + (size_t)n * 4, &todo))) return rc;
-    F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, h, w, nclasses, fa, threshold, classes, votes_u16,
-                                 ctx->dev_err, perm, gather, tiled, (unsigned int*)todo, (int32_t*)((char*)todo + 16), s));
+    F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,
+                                 ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), s));
     return F3D_OK;
 }
 
@@ -509,7 +509,7 @@ int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
         F3D_HIP(ctx, hipMemcpyAsync(dmasks, masks, mbytes, hipMemcpyHostToDevice, s));
     }
     // NumPy callers hand over clouds in arbitrary order: cell-sort large ones (results are order-independent)
-    const unsigned flags = (n >= 65536 ? F3D_FUSE_SORT : 0u) | ((int64_t)n * 16 >= (int64_t)h * w ? F3D_FUSE_TILE_MASKS : 0u);
+    const unsigned flags = n >= 65536 ? F3D_FUSE_SORT : 0u;
     if ((rc = f3d_project_vote_argmax_dev(ctx, dxyz, dtype, n, (const f3d_view*)dviews, nviews, (const uint8_t*)dmasks, h, w,
                                           nclasses, filter, nfilter, threshold, (int64_t*)dcls, (uint16_t*)dvotes, flags,
                                           nullptr, s)))

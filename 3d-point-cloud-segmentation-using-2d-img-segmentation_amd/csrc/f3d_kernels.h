@@ -39,13 +39,17 @@ size_t f3d_fuse_lds_bytes(int mode, int nclasses);
 int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
 // perm (device, may be NULL): caller-order index of sorted point i.  gather_xyz = false: xyz is already the sorted copy;
 // gather_xyz = true: xyz is the caller's cloud and the kernel reads point perm[i].  todo_count / todo: device scratch
-// (1 counter + n int32) for the points the fast kernel hands to the exact kernel.
+// (1 counter + n int32) for the points the fast kernel hands to the exact kernel.  masks: the caller's [V,H,W] labels
+// (read by the exact kernel); cmasks: their coded, tiled copy made by f3d_launch_code_masks (read by the fast kernel),
+// or NULL when nclasses > F3D_CODE_MAX_NCLASSES -- the exact kernel then labels every point.
+#define F3D_CODE_MAX_NCLASSES 253            // labels 0..nclasses + "rejected" + "no sample" must fit the 256 byte codes
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
-                           const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled,
+                           const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
+                           double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
                            unsigned int* todo_count, int32_t* todo, hipStream_t s);
-// masks [V,H,W] row-major -> 8x8-pixel tiles (H, W multiples of 8)
-hipError_t f3d_launch_tile_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, hipStream_t s);
+// masks [V,H,W] row-major labels -> 8x8-pixel tiles of vote-bin codes (any H, W); dst holds f3d_coded_masks_bytes()
+size_t f3d_coded_masks_bytes(int nviews, int h, int w);
+hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, hipStream_t s);
 // audit of the fast projection (tests only): for every (point, view) pair inside the frustum counts
 // stats[0] pairs, stats[1] pairs sent to the exact fallback, stats[2] accepted pairs whose floor differs from the
 // canonical path (must stay 0), stats[3] pairs rejected/accepted by the f32 cull that the exact test contradicts (0)

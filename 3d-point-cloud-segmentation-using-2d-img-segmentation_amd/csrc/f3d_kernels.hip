@@ -130,25 +130,51 @@ __device__ __forceinline__ void cull_point32(const f3d_view& vw, float px, float
     sure = sr & small;
 }
 
-// byte offset of pixel (iu, iv) inside one view's mask: row-major as the caller hands it over, or the 8x8-pixel tiled copy
-// (one 64-B line per tile) made by k_tile_masks -- neighbouring points of a wave then share cache lines in BOTH directions
+// byte offset of pixel (iu, iv) inside one view's mask: row-major as the caller hands it over (the exact kernel), or in
+// the 8x8-pixel tiled copy (one 64-B line per tile) made by k_code_masks -- neighbouring points of a wave then share
+// cache lines in BOTH directions
 template <bool TILED>
-__device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W) {
-    if (TILED) return (((unsigned)(iv >> 3) * (unsigned)(W >> 3) + (unsigned)(iu >> 3)) << 6) | ((unsigned)(iv & 7) << 3) | (unsigned)(iu & 7);
+__device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W) {          // TILED: W = tiles per row
+    if (TILED) return (((unsigned)(iv >> 3) * (unsigned)W + (unsigned)(iu >> 3)) << 6) | ((unsigned)(iv & 7) << 3) | (unsigned)(iu & 7);
     return (unsigned)(iv * W + iu);
 }
 
-// [V,H,W] row-major -> [V][H/8][W/8][8][8]; one thread moves 8 bytes (one tile row), a wave writes 512 contiguous bytes
-__global__ __launch_bounds__(F3D_BLOCK) void k_tile_masks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int V, int H, int W) {
-    const int64_t per_view = (int64_t)H * W / 8;                    // 8-byte pieces per view
+// Bin codes of the fast kernel's vote histogram (nclasses <= F3D_CODE_MAX_NCLASSES): label l <= nclasses lives in bin
+// nclasses + 2 - l (so that, among equal counts, the LARGER code is the smaller label), any label > nclasses (IndexError
+// in the reference) in bin 1, and bin 0 means "no sample": k_code_masks ends every view with 64 such bytes, and a lane
+// without a pixel gathers from there instead of carrying a validity flag through the vote.
+#define F3D_CODE_NONE 0u
+#define F3D_CODE_BAD 1u
+__host__ __device__ inline size_t f3d_coded_plane(int H, int W) { return (size_t)((H + 7) >> 3) * (size_t)((W + 7) >> 3) * 64 + 64; }
+
+// [V,H,W] row-major labels -> [V][ceil(H/8)][ceil(W/8)][8][8] bin codes + the 64-B "no sample" tail; one thread moves one
+// tile row (8 bytes), a wave writes 512 contiguous bytes.  VEC: W % 8 == 0 and src 8-B aligned (one 8-B load per thread).
+template <bool VEC>
+__global__ __launch_bounds__(F3D_BLOCK) void k_code_masks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int V, int H, int W,
+                                                           int nclasses) {
+    const int tw = (W + 7) >> 3, th = (H + 7) >> 3;
+    const int64_t per_view = (int64_t)th * tw * 8 + 8;             // 8-byte pieces per view, tail included
     const int64_t total = per_view * V;
-    const int tw = W >> 3;
+    const size_t tplane = f3d_coded_plane(H, W);
     for (int64_t k = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; k < total; k += (int64_t)gridDim.x * F3D_BLOCK) {
         const int64_t v = k / per_view; const int64_t r = k - v * per_view;      // r indexes (tile, row-in-tile) of the destination
+        uint64_t out = 0;                                                         // tail pieces and padding: F3D_CODE_NONE
         const int tile = (int)(r >> 3), ry = (int)(r & 7);
         const int ty = tile / tw, tx = tile - ty * tw;
-        const uint64_t x = *reinterpret_cast<const uint64_t*>(src + (size_t)v * H * W + (size_t)(ty * 8 + ry) * W + tx * 8);
-        *reinterpret_cast<uint64_t*>(dst + (size_t)v * H * W + (size_t)r * 8) = x;
+        const int y = ty * 8 + ry;
+        if (ty < th && y < H) {
+            const uint8_t* row = src + (size_t)v * H * W + (size_t)y * W + tx * 8;
+            uint64_t x = 0;
+            if (VEC) x = *reinterpret_cast<const uint64_t*>(row);
+            else for (int c = 0; c < 8; ++c) if (tx * 8 + c < W) x |= (uint64_t)row[c] << (8 * c);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned l = (unsigned)(x >> (8 * c)) & 0xFFu;
+                const unsigned b = l <= (unsigned)nclasses ? (unsigned)nclasses + 2u - l : F3D_CODE_BAD;
+                out |= (uint64_t)b << (8 * c);
+            }
+        }
+        *reinterpret_cast<uint64_t*>(dst + (size_t)v * tplane + (size_t)r * 8) = out;
     }
 }
 
@@ -257,6 +283,71 @@ __device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const u
     }
 }
 
+// ---- the fast kernel's vote: `b` is a bin code read from the coded masks (see k_code_masks).  No validity flag, no label
+// range test: "no sample" adds 0 to bin 0 and yields key 0, a label the reference would reject lands in bin 1 and is
+// reported by finish_coded.  key = (count before this vote << 16) | code: its running maximum is the plurality, ties
+// going to the smaller label (the larger code), exactly the first-maximum rule of np.argmax.
+struct coded_state {
+    unsigned total = 0;
+    unsigned best = 0;
+};
+
+template <int MODE>
+__device__ __forceinline__ void vote_coded(coded_state& st, uint32_t* hist, int tid, unsigned b) {
+    using HT = hist_traits<MODE>;
+    const unsigned one = b < 1u ? b : 1u;                                          // 0 for F3D_CODE_NONE
+    st.total += one;
+    const unsigned sh = (b & (HT::per_word - 1)) * HT::bits;
+    const uint32_t old = atomicAdd(&hist[((b >> HT::shift) * F3D_BLOCK) | (unsigned)tid], one << sh);
+    const unsigned key = (((old >> sh) & HT::mask) << 16) | b;
+    st.best = st.best > key ? st.best : key;
+}
+
+template <int MODE>
+__device__ __forceinline__ unsigned coded_count(const uint32_t* hist, int tid, unsigned b) {
+    using HT = hist_traits<MODE>;
+    return (hist[((b >> HT::shift) * F3D_BLOCK) | (unsigned)tid] >> ((b & (HT::per_word - 1)) * HT::bits)) & HT::mask;
+}
+
+// VotingSegmentation.segment (voting.py:120-135) for one point of the fast kernel, then the stores; returns whether a label
+// the reference would raise IndexError for was sampled
+template <int MODE, bool WRITE_VOTES>
+__device__ __forceinline__ bool finish_coded(const coded_state& st, const uint32_t* hist, int tid, const f3d_filter_args& flt,
+                                             int nclasses, double threshold, bool store, int64_t orig,
+                                             int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out) {
+    const int ncols = nclasses + 1;
+    const unsigned top = (unsigned)nclasses + 2u;                                  // code of label 0
+    int64_t cls;
+    int win_c, win_i;
+    if (flt.nfilter > 0) {                                                         // votes[:, filter_classes]: first maximum wins
+        win_c = -1; win_i = 0;
+        for (int k = 0; k < flt.nfilter; ++k) {
+            const int l = filter_at(flt, k);
+            int c = 0;
+            if (l >= 0 && l < ncols) c = (int)coded_count<MODE>(hist, tid, top - (unsigned)l);
+            if (c > win_c) { win_c = c; win_i = k; }
+        }
+    } else {
+        win_c = (int)(st.best >> 16) + 1; win_i = (int)(top - (st.best & 0xFFFFu));
+    }
+    if (st.total == 0) cls = nclasses;                                             // :126
+    else {
+        cls = win_i;
+        if ((double)win_c / (double)st.total < threshold) cls = nclasses;          // :128-130
+        if (win_c == 0) cls = nclasses;                                            // :131
+    }
+    if (flt.nfilter > 0) {                                                         // sequential remap (Q3)
+        int64_t r = cls;
+        for (int k = 0; k < flt.nfilter; ++k) if (r == k) r = filter_at(flt, k);
+        cls = r;
+    }
+    if (store) classes[orig] = cls;
+    if (WRITE_VOTES && store) {
+        for (int l = 0; l < ncols; ++l) votes_out[(size_t)orig * ncols + l] = (uint16_t)coded_count<MODE>(hist, tid, top - (unsigned)l);
+    }
+    return coded_count<MODE>(hist, tid, F3D_CODE_BAD) != 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_fuse: the fast kernel.  It contains NO exact arithmetic: a point for which any accelerator cannot prove its
 // decision (a plane within the float32 margin, a pixel within the fast-projection bound of an integer, huge or
@@ -264,10 +355,10 @@ __device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const u
 // right behind, recomputes that point entirely with the reference's arithmetic (about 1e-3 of the points of a
 // random cloud).  Keeping the canonical sequences out of this kernel is what keeps its register budget small.
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE, bool WRITE_VOTES, bool TILED>
+template <typename T, int MODE, bool WRITE_VOTES>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
-                                                     const uint8_t* __restrict__ masks, int H, int W,
+                                                     const uint8_t* __restrict__ cmasks, int H, int W,
                                                      int nclasses, f3d_filter_args flt, double threshold,
                                                      int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
                                                      int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
@@ -278,9 +369,11 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
     uint32_t* hist = lds_u32 + 64 * F3D_CULL_ROW;                         // [words_per_thread][F3D_BLOCK]
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
     const int ncols = nclasses + 1;
-    const int words = (ncols + 1 + HT::per_word - 1) >> HT::shift;       // + 1: the spare bin of the branch-free vote
+    const int words = (ncols + 2 + HT::per_word - 1) >> HT::shift;       // + 2: codes F3D_CODE_NONE and F3D_CODE_BAD
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
-    const size_t plane = (size_t)H * (size_t)W;
+    const size_t plane = f3d_coded_plane(H, W);                           // bytes per view of the coded, tiled masks
+    const int wt = (W + 7) >> 3;                                          // tiles per row
+    const unsigned none_off = (unsigned)(plane - 64);                     // where a lane without a pixel gathers F3D_CODE_NONE
     const int ngroups = (nviews + 63) >> 6;
     const double umax = (double)(W > H ? W : H);
 
@@ -328,12 +421,11 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         const float ps_box = ((fabsf(c0) + fabsf(c1)) + fabsf(c2)) + ((e0 + e1) + e2);
 
         for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;       // own column only: no barrier
-        vote_state<MODE> st;
-        bool pend = false;                                  // software-pipelined gather: vote one view later
-        int pend_label = 0;
-        int cpend[F3D_CHUNK], clabel[F3D_CHUNK];
+        coded_state st;
+        unsigned pend_code = F3D_CODE_NONE;                 // software-pipelined gather: vote one view later
+        unsigned ccode[F3D_CHUNK];
 #pragma unroll
-        for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = -1; clabel[k] = 0; }
+        for (int k = 0; k < F3D_CHUNK; ++k) ccode[k] = F3D_CODE_NONE;
 
         for (int g = 0; g < ngroups; ++g) {
             if (ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
@@ -362,10 +454,10 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
             // (in-kernel stamps showed ~90 % of a view iteration waiting for the previous gather with a 1-deep pipeline).
             unsigned long long todo_v = valid_m & ~out_m & in_m;
             while (todo_v) {
-                int cv[F3D_CHUNK], coff[F3D_CHUNK];          // coff < 0: no sample (validity travels as the sign bit, not as a bool)
+                int cv[F3D_CHUNK]; unsigned coff[F3D_CHUNK];
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) {
-                    cv[k] = 0; coff[k] = -1;
+                    cv[k] = 0; coff[k] = none_off;
                     if (todo_v) {
                         const int bit = __builtin_ctzll(todo_v);
                         todo_v &= todo_v - 1ull;
@@ -375,16 +467,16 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                         bool unsure;
                         const bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live & small;
                         defer = defer | (unsure & live);
-                        cv[k] = v; coff[k] = hit ? (int)mask_offset<TILED>(iu, iv, W) : -1;
+                        cv[k] = v; coff[k] = hit ? mask_offset<true>(iu, iv, wt) : none_off;
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < F3D_CHUNK; ++k) vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k] >= 0, clabel[k]);
+                for (int k = 0; k < F3D_CHUNK; ++k) vote_coded<MODE>(st, hist, tid, ccode[k]);
 #pragma unroll
-                for (int k = 0; k < F3D_CHUNK; ++k) { cpend[k] = coff[k]; clabel[k] = (masks + (size_t)cv[k] * plane)[max(coff[k], 0)]; }
+                for (int k = 0; k < F3D_CHUNK; ++k) ccode[k] = (cmasks + (size_t)cv[k] * plane)[coff[k]];
             }
 #pragma unroll
-            for (int k = 0; k < F3D_CHUNK; ++k) { vote_add<MODE>(st, hist, tid, flt, nclasses, cpend[k] >= 0, clabel[k]); cpend[k] = -1; }
+            for (int k = 0; k < F3D_CHUNK; ++k) { vote_coded<MODE>(st, hist, tid, ccode[k]); ccode[k] = F3D_CODE_NONE; }
             // mixed views: per-point float32 cull; a lane inside the rounding margin of a plane is deferred
             todo_v = valid_m & ~out_m & ~in_m;
             while (todo_v) {
@@ -411,22 +503,21 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                     hit = project_fast(vw, p, W, H, umax, iu, iv, unsure);
                     defer = defer | unsure;
                 }
-                vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);
-                pend = hit;
-                pend_label = (masks + (size_t)v * plane)[hit ? mask_offset<TILED>(iu, iv, W) : 0u];
+                vote_coded<MODE>(st, hist, tid, pend_code);
+                pend_code = (cmasks + (size_t)v * plane)[hit ? mask_offset<true>(iu, iv, wt) : none_off];
             }
         }
-        vote_add<MODE>(st, hist, tid, flt, nclasses, pend, pend_label);
-        if (st.bad & !defer) atomicOr(err, F3D_DEVERR_INDEX);
+        vote_coded<MODE>(st, hist, tid, pend_code);
         if (defer) todo[atomicAdd(todo_count, 1u)] = (int32_t)(gather_xyz ? orig : i);     // index into xyz as this launch sees it
-        finish_point<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live & !defer, orig, classes, votes_out);
+        const bool bad = finish_coded<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live & !defer, orig, classes, votes_out);
+        if (bad & !defer) atomicOr(err, F3D_DEVERR_INDEX);
     }
 }
 
 // k_fuse_exact: the reference's arithmetic, nothing else, for the points k_fuse deferred (and the whole path of the
 // oracle in kernel form): exact 5-plane test, canonical projection with IEEE divisions, gather, vote, segment.
-template <typename T, int MODE, bool WRITE_VOTES, bool TILED>
-__global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ xyz, const unsigned int* __restrict__ todo_count,
+template <typename T, int MODE, bool WRITE_VOTES>
+__global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ xyz, int64_t n_all, const unsigned int* __restrict__ todo_count,
                                                            const int32_t* __restrict__ todo,
                                                            const f3d_view* __restrict__ views, int nviews,
                                                            const uint8_t* __restrict__ masks, int H, int W,
@@ -441,11 +532,11 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ 
     const int ncols = nclasses + 1;
     const int words = (ncols + 1 + HT::per_word - 1) >> HT::shift;
     const size_t plane = (size_t)H * (size_t)W;
-    const int64_t count = (int64_t)*todo_count;
+    const int64_t count = todo ? (int64_t)*todo_count : n_all;                  // todo == NULL: every point (no fast kernel ran)
     for (int64_t base = (int64_t)blockIdx.x * F3D_BLOCK; base < count; base += (int64_t)gridDim.x * F3D_BLOCK) {
         const int64_t k = base + tid;
         const bool live = k < count;
-        const int64_t src = live ? (int64_t)todo[k] : 0;                          // index into xyz as k_fuse saw it
+        const int64_t src = live ? (todo ? (int64_t)todo[k] : k) : 0;             // index into xyz as k_fuse saw it
         const int64_t orig = (live && perm && !gather_xyz) ? (int64_t)perm[src] : src;
         f3d_p3 p = {0.0, 0.0, 0.0};
         if (live) p = load_point(xyz, src);
@@ -459,7 +550,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ 
                 double fu, fv;
                 project_exact(vw, p, fu, fv);
                 if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) {   // NaN compares false
-                    hit = true; off = mask_offset<TILED>((int)fu, (int)fv, W);
+                    hit = true; off = mask_offset<false>((int)fu, (int)fv, W);
                 }
             }
             const int label = hit ? (int)(masks + (size_t)v * plane)[off] : 0;
@@ -780,7 +871,7 @@ hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, co
 size_t f3d_fuse_lds_bytes(int mode, int nclasses) {
     const int ncols = nclasses + 1;
     const int per_word = (mode == MODE_HIST8) ? 4 : 2;
-    const size_t hist = (size_t)((ncols + 1 + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);   // + the spare bin
+    const size_t hist = (size_t)((ncols + 2 + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);   // + codes NONE and BAD
     return 64 * F3D_CULL_ROW * sizeof(float) + hist;
 }
 
@@ -792,8 +883,8 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
 }
 
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
-                           const uint8_t* masks, int h, int w, int nclasses, const f3d_filter_args& flt, double threshold,
-                           int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz, bool tiled,
+                           const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
+                           double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
                            unsigned int* todo_count, int32_t* todo, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);
@@ -803,21 +894,24 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
     int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID);
     grid = (grid + 7) & ~7;                                  // the XCD-aware tile mapping needs a multiple of 8 blocks
-    const dim3 g(grid), b(F3D_BLOCK), ge(512);
-    hipError_t e0 = hipMemsetAsync(todo_count, 0, sizeof(unsigned int), s);
-    if (e0 != hipSuccess) return e0;
-#define F3D_FUSE2(T, M, V, TL)                                                                                 \
+    const bool fast = cmasks != nullptr;                     // no coded masks (nclasses > F3D_CODE_MAX_NCLASSES): exact kernel only
+    const dim3 g(grid), b(F3D_BLOCK), ge(fast ? 512 : grid);
+    if (fast) {
+        hipError_t e0 = hipMemsetAsync(todo_count, 0, sizeof(unsigned int), s);
+        if (e0 != hipSuccess) return e0;
+    }
+#define F3D_FUSE(T, M, V)                                                                                      \
     do {                                                                                                       \
         if (lds > 64 * 1024) {                                                                                 \
-            (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            (void)hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact); \
+            (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact); \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_fuse<T, M, V, TL>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, masks, h, w, \
-                           nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo); \
-        hipLaunchKernelGGL((k_fuse_exact<T, M, V, TL>), ge, b, lds_exact, s, (const T*)xyz, todo_count, todo, views_dev, nviews, \
-                           masks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0); \
+        if (fast)                                                                                              \
+            hipLaunchKernelGGL((k_fuse<T, M, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, \
+                               nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo); \
+        hipLaunchKernelGGL((k_fuse_exact<T, M, V>), ge, b, lds_exact, s, (const T*)xyz, n, todo_count, fast ? todo : nullptr, \
+                           views_dev, nviews, masks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0); \
     } while (0)
-#define F3D_FUSE(T, M, V) do { if (tiled) F3D_FUSE2(T, M, V, true); else F3D_FUSE2(T, M, V, false); } while (0)
 #define F3D_FUSE_T(T)                                                                                          \
     do {                                                                                                       \
         if (mode == MODE_HIST8) { if (votes) F3D_FUSE(T, MODE_HIST8, true); else F3D_FUSE(T, MODE_HIST8, false); } \
@@ -826,15 +920,18 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     if (dtype == F3D_F64) F3D_FUSE_T(double); else F3D_FUSE_T(float);
 #undef F3D_FUSE_T
 #undef F3D_FUSE
-#undef F3D_FUSE2
     return hipGetLastError();
 }
 
-hipError_t f3d_launch_tile_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, hipStream_t s) {
+size_t f3d_coded_masks_bytes(int nviews, int h, int w) { return (size_t)nviews * f3d_coded_plane(h, w); }
+
+hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, hipStream_t s) {
     if (nviews <= 0) return hipSuccess;
-    if ((h & 7) || (w & 7) || ((uintptr_t)src & 7) || ((uintptr_t)dst & 7)) return hipErrorInvalidValue;
-    const int64_t total = (int64_t)nviews * h * w / 8;
-    hipLaunchKernelGGL(k_tile_masks, dim3(grid_for(total, F3D_BLOCK, F3D_GRID_CAP)), dim3(F3D_BLOCK), 0, s, src, dst, nviews, h, w);
+    if (nclasses < 0 || nclasses > F3D_CODE_MAX_NCLASSES || ((uintptr_t)dst & 7)) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)nviews * (int64_t)(f3d_coded_plane(h, w) / 8);
+    const dim3 g(grid_for(total, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+    if (!(w & 7) && !((uintptr_t)src & 7)) hipLaunchKernelGGL(k_code_masks<true>, g, b, 0, s, src, dst, nviews, h, w, nclasses);
+    else hipLaunchKernelGGL(k_code_masks<false>, g, b, 0, s, src, dst, nviews, h, w, nclasses);
     return hipGetLastError();
 }
 

@@ -16,10 +16,10 @@ from pathlib import Path
 import numpy as np
 
 __all__ = ['F3DError', 'F3DUnavailable', 'Context', 'default_context', 'library', 'library_path',
-           'views_build', 'frustum_data', 'quat_inverse', 'VIEW_DOUBLES', 'F64', 'F32', 'FUSE_SORT', 'FUSE_GATHER', 'FUSE_TILE_MASKS']
+           'views_build', 'frustum_data', 'quat_inverse', 'VIEW_DOUBLES', 'F64', 'F32', 'FUSE_SORT', 'FUSE_GATHER']
 
 F64, F32 = 0, 1
-FUSE_SORT, FUSE_GATHER, FUSE_TILE_MASKS = 2, 4, 8
+FUSE_SORT, FUSE_GATHER = 2, 4
 OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_ZERO_QUAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 VIEW_DOUBLES = 80            # sizeof(f3d_view) / 8
 OBB_DOUBLES = 15             # sizeof(f3d_obb) / 8

@@ -48,7 +48,6 @@ def parse():
     ap.add_argument('--cpu-sample', type=int, default=5_000_000, help='points of the CPU-baseline slice (all views)')
     ap.add_argument('--sorted', action='store_true', help='experiment: hand the cloud over already in grid-cell order (host sort)')
     ap.add_argument('--no-sort', action='store_true', help='do not cell-sort the cloud inside the step')
-    ap.add_argument('--no-tile', action='store_true', help='gather from the row-major masks instead of an 8x8-tiled copy made in the step')
     ap.add_argument('--prepared', action='store_true', help='cell-sort once outside the timed loop and keep the sorted cloud resident')
     return ap.parse_args()
 
@@ -136,7 +135,7 @@ def main():
     stream = torch.cuda.Stream(dev)          # a real (non-null) HIP stream: kernels, RCCL and the timing events all use it
     torch.cuda.set_stream(stream)
 
-    flags = 0 if args.no_tile else f3d.FUSE_TILE_MASKS
+    flags = 0
     perm_ptr = None
     layout = 'caller order, cell-sorted inside every step (F3D_FUSE_SORT)'
     if args.prepared:
@@ -208,7 +207,7 @@ def main():
                                                                      stream.cuda_stream), k_iters, stream)
         t_kernel = time_kernel(torch, lambda: ctx.project_vote_argmax_dev(
             xyz.data_ptr(), dtype, n, views.data_ptr(), V, masks_full.data_ptr(), S, S, 133, 0.5, flt, classes.data_ptr(), None,
-            stream.cuda_stream, flags=f3d.FUSE_GATHER | (flags & f3d.FUSE_TILE_MASKS), perm_ptr=perm_t.data_ptr()), k_iters, stream)
+            stream.cuda_stream, flags=f3d.FUSE_GATHER, perm_ptr=perm_t.data_ptr()), k_iters, stream)
     else:
         t_kernel = time_kernel(torch, fuse, k_iters, stream)
     xyz_b = 12 if args.f32 else 24

@@ -162,15 +162,15 @@ int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
  *                     caller's order.  `perm` must be NULL.
  *   F3D_FUSE_GATHER   with `perm`: xyz is still the caller-order cloud and the kernel reads point
  *                     perm[i] (what F3D_FUSE_SORT does internally; lets a caller time / reuse the sort).
- *   F3D_FUSE_TILE_MASKS  copy the masks into 8x8-pixel tiles (one cache line each) inside the call, when H and W
- *                     are multiples of 8: the 1-byte gathers of neighbouring points then share lines in both
- *                     image directions (one extra pass over the masks; pays off when n * V >> V * H * W / 16).
+ * Every call first copies the masks into context scratch as 8x8-pixel tiles (one cache line each) of vote-bin
+ * codes -- one extra pass over V*H*W bytes; the 1-byte gathers of neighbouring points then share lines in both
+ * image directions.  With nclasses > 253 (no byte left for the "no sample" and "rejected label" codes) the
+ * accelerated kernel is skipped and the reference-arithmetic kernel labels every point.
  * perm (device, may be NULL): perm[i] is the caller-order index of the i-th point in cell order
  * (from f3d_cloud_sort_cells_dev); without F3D_FUSE_GATHER xyz must be the sorted copy.
  * classes/votes are always written at caller-order indices. */
 #define F3D_FUSE_SORT    2u
 #define F3D_FUSE_GATHER  4u
-#define F3D_FUSE_TILE_MASKS 8u
 int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
                                 const f3d_view* views_dev /*device [V]*/, int nviews,
                                 const uint8_t* masks, int h, int w,

@@ -259,7 +259,7 @@ def filter_remap_table(nclasses, filter_classes, size):
 # ----------------------------------------------------------------------------
 # composed forward path (SURVEY 8(c) last row): project -> sample -> vote -> segment
 # ----------------------------------------------------------------------------
-def forward_votes(points, K, wxyzs, translations, masks, max_depth, w=None, h=None, out_dtype=np.float64):
+def forward_votes(points, K, wxyzs, translations, masks, max_depth, w=None, h=None, out_dtype=np.float64, ncols=None):
     """Per view j: inside = point_inside_polyhedra(P, planes_j); uv = points2pixel(P[inside]);
     drop samples with u not in [0,W) or v not in [0,H); votes[idx, mask_j[v,u]] += 1.
     (fusion.py:254-266 + voting.py:94-98 with one sample per point per view.)"""
@@ -269,7 +269,8 @@ def forward_votes(points, K, wxyzs, translations, masks, max_depth, w=None, h=No
     w = W if w is None else w
     h = H if h is None else h
     ppts, pnrm = frustum_planes(K, w, h, wxyzs, translations, max_depth)
-    ncols = 134 if masks.dtype == np.uint8 else int(masks.max()) + 1
+    if ncols is None:                                                   # VotingSegmentation allocates nclasses + 1 columns (voting.py:34)
+        ncols = 134 if masks.dtype == np.uint8 else int(masks.max()) + 1
     votes = np.zeros((len(P), ncols), out_dtype)
     for j in range(V):
         inside = point_inside_polyhedra(P, ppts[j], pnrm[j])
@@ -288,7 +289,7 @@ def forward_votes(points, K, wxyzs, translations, masks, max_depth, w=None, h=No
 
 def project_vote_argmax(points, K, wxyzs, translations, masks, max_depth, nclasses=133,
                         threshold=0.5, filter_classes=None, return_votes=False):
-    votes = forward_votes(points, K, wxyzs, translations, masks, max_depth)[:, :nclasses + 1]
+    votes = forward_votes(points, K, wxyzs, translations, masks, max_depth, ncols=nclasses + 1)
     cls = segment(votes, nclasses, threshold, filter_classes)
     return (cls, votes) if return_votes else cls
 

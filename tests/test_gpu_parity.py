@@ -174,12 +174,14 @@ def test_vote_and_segment_larger_random(ctx):
         assert np.array_equal(ctx.segment_votes(votes, 133, thr, flt), O.segment(want, 133, thr, flt))
 
 
-def _dev_fuse(ctx, pts, views, masks, flt, thr, flags, presort=False, f32=False):
+def _dev_fuse(ctx, pts, views, masks, flt, thr, flags, presort=False, f32=False, nclasses=133, mask_shift=0):
     import torch
     dev = torch.device('cuda', 0)
     x = torch.from_numpy(pts.astype(np.float32) if f32 else pts).to(dev)
     vd = torch.from_numpy(views).to(dev)
-    md = torch.from_numpy(masks).to(dev)
+    mbuf = torch.zeros(masks.size + mask_shift, dtype=torch.uint8, device=dev)      # mask_shift: misaligned mask pointer
+    md = mbuf[mask_shift:].view(masks.shape)
+    md.copy_(torch.from_numpy(masks))
     n = len(pts)
     cls = torch.full((n,), -7, dtype=torch.int64, device=dev)
     s = torch.cuda.Stream(dev)
@@ -195,7 +197,7 @@ def _dev_fuse(ctx, pts, views, masks, flt, thr, flags, presort=False, f32=False)
             assert np.array_equal(xs.cpu().numpy(), x.cpu().numpy()[perm.cpu().numpy()])
             x, perm_ptr = xs, perm.data_ptr()
         V, H, W = masks.shape
-        ctx.project_vote_argmax_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, md.data_ptr(), H, W, 133, thr, flt,
+        ctx.project_vote_argmax_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, md.data_ptr(), H, W, nclasses, thr, flt,
                                     cls.data_ptr(), None, s.cuda_stream, flags=flags, perm_ptr=perm_ptr)
         ctx.take_device_error(s.cuda_stream)
         s.synchronize()
@@ -207,7 +209,7 @@ def test_device_api_sort_flags_and_prepared_layout(ctx):
     views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
     want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
                                  133, 0.5, None)
-    for flags in (0, f3d.FUSE_SORT, f3d.FUSE_TILE_MASKS, f3d.FUSE_SORT | f3d.FUSE_TILE_MASKS):
+    for flags in (0, f3d.FUSE_SORT):
         assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, flags), want), flags
     assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, 0, presort=True), want)
     assert np.array_equal(_dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.5, f3d.FUSE_SORT, f32=True), want)
@@ -299,7 +301,7 @@ def _full_size_case(ctx, name, mask_kind, flt, subset=60_000):
     sc = synth.scene(name, mask_kind=mask_kind)
     pts, n = sc['points'], len(sc['points'])
     views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
-    labels = _dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, f3d.FUSE_SORT | f3d.FUSE_TILE_MASKS)
+    labels = _dev_fuse(ctx, pts, views, sc['masks'], flt, 0.5, f3d.FUSE_SORT)
     assert labels.min() >= 0 and labels.max() <= 133
     # (1) the oracle on a random subset agrees with the full run at those indices (labels are per-point functions)
     rng = np.random.default_rng(123)
@@ -341,14 +343,44 @@ def test_config_c1_full_vs_oracle(ctx):
         assert np.array_equal(ctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, thr, flt), want)
 
 
-def test_mask_tiling_falls_back_for_odd_sizes_and_matches(ctx):
+def test_mask_coding_any_size_and_alignment(ctx):
+    """k_code_masks: 8x8 tiles of bin codes for any H, W (padded tiles) and any mask pointer alignment."""
     rng = np.random.default_rng(8)
     q, t = synth.ring_views(6)
     pts = synth.cloud(40_000)
-    for (h, w) in [(60, 100), (64, 104), (1, 8)]:                     # 60 is not a multiple of 8 -> row-major path; 64x104 -> tiled
+    for (h, w, shift) in [(60, 100, 0), (61, 99, 0), (64, 104, 3), (64, 104, 0), (1, 8, 0), (3, 5, 1)]:
         K = np.array([[w * 0.8, 0, w / 2], [0, w * 0.8, h / 2], [0, 0, 1]])
         masks = rng.integers(0, 134, (6, h, w), dtype=np.uint8)
         views = f3d.views_build(K, w, h, q, t, 10.0)
         want = O.project_vote_argmax(pts, K, q, t, masks, 10.0, 133, 0.3, None)
-        for flags in (0, f3d.FUSE_TILE_MASKS, f3d.FUSE_TILE_MASKS | f3d.FUSE_SORT):
-            assert np.array_equal(_dev_fuse(ctx, pts, views, masks, None, 0.3, flags), want), (h, w, flags)
+        for flags in (0, f3d.FUSE_SORT):
+            assert np.array_equal(_dev_fuse(ctx, pts, views, masks, None, 0.3, flags, mask_shift=shift), want), (h, w, flags)
+
+
+def test_nclasses_edge_values(ctx):
+    """nclasses = 253 is the last value with byte codes to spare (fast kernel); 254 and 255 run on the exact kernel alone;
+    a label above nclasses raises IndexError only when such a pixel is sampled."""
+    rng = np.random.default_rng(9)
+    sc = synth.scene('C1', n=30_000)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    masks = rng.integers(0, 256, sc['masks'].shape, dtype=np.uint8)
+    for ncls in (255, 254):
+        m = np.minimum(masks, ncls)
+        want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], m, sc['max_depth'], ncls, 0.3, None)
+        for flags in (0, f3d.FUSE_SORT):
+            assert np.array_equal(_dev_fuse(ctx, sc['points'], views, m, None, 0.3, flags, nclasses=ncls), want), (ncls, flags)
+    with pytest.raises(IndexError):                                    # exact-kernel-only path reports it as well
+        _dev_fuse(ctx, sc['points'], views, masks, None, 0.3, 0, nclasses=254)
+    masks253 = np.minimum(masks, 253)
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], masks253, sc['max_depth'], 253, 0.3, None)
+    assert np.array_equal(_dev_fuse(ctx, sc['points'], views, masks253, None, 0.3, f3d.FUSE_SORT, nclasses=253), want)
+    with pytest.raises(IndexError):
+        _dev_fuse(ctx, sc['points'], views, masks, None, 0.3, f3d.FUSE_SORT, nclasses=253)
+    # labels above nclasses that no point samples are harmless (voting.py:98 only sees sampled pixels)
+    pts = sc['points'][:2000]
+    loud = np.minimum(masks, 100)
+    loud[:, 0, 0] = 200
+    votes = O.forward_votes(pts, sc["K"], sc["wxyzs"], sc["translations"], loud, sc["max_depth"], ncols=256)
+    assert votes[:, 200].sum() == 0                                    # nobody looks at pixel (0, 0)
+    want = O.segment(votes[:, :101], 100, 0.3, None)
+    assert np.array_equal(_dev_fuse(ctx, pts, views, loud, None, 0.3, 0, nclasses=100), want)
