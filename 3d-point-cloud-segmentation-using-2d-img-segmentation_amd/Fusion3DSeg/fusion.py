@@ -41,6 +41,26 @@ def project_vote_argmax(points, K, wxyzs, translations, masks, max_depth=10, ncl
     return f3d.default_context().project_vote_argmax(points, views, masks, nclasses, threshold, filter_classes, return_votes)
 
 
+def radius_adjacency(points, ds_radius, as_csr=False):
+    """The adjacency ``Fusion.save_data`` stores in fusion/adj.pkl (reference :373-377):
+    ``KDTree(points).query_radius(points, r=2 * ds_radius)``, built on the GPU with a uniform grid.
+
+    Returns what the reference pickles -- an object array of int64 index arrays, one per point, itself included -- or,
+    with ``as_csr``, the (offsets int64 [N+1], neighbours int32 [E]) pair that ``split_into_instances`` also accepts
+    (no Python objects, what a 10M-point cloud wants).  Row order: by grid cell, then ascending index (sklearn's order is
+    the tree traversal's, unspecified)."""
+    if ds_radius is None:
+        return None                                                            # reference :371-372
+    offs, nbrs = f3d.default_context().radius_graph(points, 2 * ds_radius)
+    if as_csr:
+        return offs, nbrs
+    out = np.empty(len(offs) - 1, dtype=object)
+    wide = nbrs.astype(np.int64)
+    for i in range(len(out)):
+        out[i] = wide[offs[i]:offs[i + 1]]
+    return out
+
+
 class Fusion:
     def __init__(self, tof, rts, point_range=None, decimation=1, save_lookups=True):
         raise NotImplementedError('Fusion.fuse (greedy patch merge, reference fusion.py:134-324) is outside this round\'s scope; '

@@ -17,7 +17,13 @@ import f3d
 
 
 def adjacency_to_csr(adj, n):
-    """list / object array of neighbour index arrays -> (offsets int64 [n+1], neighbours int32 [E])."""
+    """list / object array of neighbour index arrays -> (offsets int64 [n+1], neighbours int32 [E]); a CSR pair
+    (as ``fusion.radius_adjacency(..., as_csr=True)`` returns it) passes through."""
+    if isinstance(adj, tuple) and len(adj) == 2:
+        offs, nbrs = np.ascontiguousarray(adj[0], np.int64), np.ascontiguousarray(adj[1], np.int32)
+        if len(offs) != n + 1:
+            raise ValueError('CSR adjacency: offsets must have n + 1 entries')
+        return offs, nbrs
     lens = np.fromiter((len(a) for a in adj), dtype=np.int64, count=n)
     offs = np.zeros(n + 1, np.int64)
     np.cumsum(lens, out=offs[1:])

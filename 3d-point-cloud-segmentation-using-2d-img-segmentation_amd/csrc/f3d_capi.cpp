@@ -2,6 +2,7 @@
 // wrappers, and the tiny per-view host geometry.  No CPU fallback: every compute entry point
 // needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -19,7 +20,7 @@ static_assert(sizeof(f3d_view) == 640, "f3d_view is 80 doubles");
 namespace {
 
 enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_SORT_PERM, SLOT_SORT_SCRATCH,
-       SLOT_TILED_MASKS, SLOT_TODO, SLOT_COUNT };
+       SLOT_TILED_MASKS, SLOT_TODO, SLOT_GRAPH, SLOT_GRAPH_BBOX, SLOT_COUNT };
 
 thread_local char g_create_err[512] = "";
 
@@ -36,6 +37,11 @@ struct f3d_ctx {
     size_t table_slots;
     int* filter_dev;                    // filter_classes lists longer than 8
     unsigned long long* count_dev;
+    // radius graph: the grid of the last count pass (the fill pass must follow it for the same cloud)
+    f3d_graphgrid graph_grid;
+    int64_t graph_n;
+    double graph_r2;
+    const void* graph_xyz;
 };
 
 namespace {
@@ -186,6 +192,7 @@ f3d_ctx* f3d_ctx_create(int device) {
     }
     if (device < 0 || device >= count) { fail(nullptr, F3D_ERR_INVALID, "device %d out of range [0,%d)", device, count); return nullptr; }
     f3d_ctx* ctx = (f3d_ctx*)calloc(1, sizeof(f3d_ctx));
+    if (ctx) ctx->graph_n = -1;
     if (!ctx) { fail(nullptr, F3D_ERR_NOMEM, "out of host memory"); return nullptr; }
     ctx->device = device;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -824,6 +831,96 @@ int f3d_components_same_class(f3d_ctx* ctx, const int64_t* classes, int64_t n, c
                                             (int64_t*)droot, s))) return rc;
     if ((rc = take_error(ctx, s))) return rc;
     F3D_HIP(ctx, hipMemcpyAsync(root, droot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (f)#1 adjacency: KDTree(points).query_radius(points, r) (fusion.py:374-375) as CSR
+// ---------------------------------------------------------------------------------------------
+int f3d_radius_graph_count_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, double radius, int64_t* offsets,
+                               int64_t* nnz, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || n > 0x7fffffffLL || !nnz || (n > 0 && (!xyz || !offsets)) || !(radius >= 0.0) || !(radius < 1e300))
+        return fail(ctx, F3D_ERR_INVALID, "radius_graph: bad arguments (n < 2^31, finite radius >= 0)");
+    *nnz = 0; ctx->graph_n = -1;
+    if (n == 0) return F3D_OK;
+    hipStream_t s = pick(ctx, stream);
+    void* dbox;
+    if ((rc = ensure(ctx, SLOT_GRAPH_BBOX, f3d_graph_bbox_bytes(), &dbox))) return rc;
+    int nb = 0;
+    F3D_HIP(ctx, f3d_launch_graph_bbox(xyz, dtype, n, dbox, &nb, s));
+    std::vector<char> hbox(f3d_graph_bbox_bytes());
+    F3D_HIP(ctx, hipMemcpyAsync(hbox.data(), dbox, hbox.size(), hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    double lo[3], hi[3];
+    if (f3d_graph_reduce_bbox(hbox.data(), nb, lo, hi))
+        return fail(ctx, F3D_ERR_INVALID, "radius_graph: the cloud contains NaN or infinity (sklearn's KDTree raises ValueError)");
+    // cell edge: a hair above the radius (two points within r are then provably in adjacent cells whatever the rounding of
+    // the cell index), grown until every axis has <= 1024 cells and the table <= 2^24 cells
+    f3d_graphgrid g;
+    double cell = radius * 1.000001 + 1e-300;
+    double ext[3];
+    for (int c = 0; c < 3; ++c) { ext[c] = hi[c] - lo[c]; if (!(ext[c] < 1e300)) return fail(ctx, F3D_ERR_INVALID, "radius_graph: extent overflow"); }
+    for (;;) {
+        double cells = 1.0; bool ok = true;
+        for (int c = 0; c < 3; ++c) { const double d = floor(ext[c] / cell) + 1.0; if (!(d <= 1024.0)) ok = false; cells *= d; }
+        if (ok && cells <= 16777216.0) break;
+        cell *= 1.25;
+    }
+    for (int c = 0; c < 3; ++c) { g.lo[c] = lo[c]; g.dim[c] = (int)(floor(ext[c] / cell) + 1.0); }
+    g.inv_cell = 1.0 / cell; g.pad = 0;
+    const int64_t ncells = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    void* scratch;
+    if ((rc = ensure(ctx, SLOT_GRAPH, f3d_graph_scratch_bytes(n, ncells), &scratch))) return rc;
+    const double r2 = radius * radius;                                     // sklearn: reduced radius = r ** 2
+    F3D_HIP(ctx, f3d_launch_graph_count(xyz, dtype, n, g, r2, scratch, offsets, s));
+    F3D_HIP(ctx, hipMemcpyAsync(nnz, offsets + n, 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    ctx->graph_grid = g; ctx->graph_n = n; ctx->graph_r2 = r2; ctx->graph_xyz = xyz;
+    return F3D_OK;
+}
+
+int f3d_radius_graph_fill_dev(f3d_ctx* ctx, int64_t n, const int64_t* offsets, int32_t* nbrs, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n != ctx->graph_n || n < 0) return fail(ctx, F3D_ERR_INVALID, "radius_graph_fill: call f3d_radius_graph_count for this cloud first");
+    if (n == 0) return F3D_OK;
+    if (!offsets || !nbrs) return fail(ctx, F3D_ERR_INVALID, "radius_graph_fill: bad arguments");
+    F3D_HIP(ctx, f3d_launch_graph_fill(n, ctx->graph_grid, ctx->graph_r2, ctx->slot[SLOT_GRAPH], offsets, nbrs, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_radius_graph_count(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, double radius, int64_t* offsets, int64_t* nnz) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || !nnz || (n > 0 && (!xyz || !offsets))) return fail(ctx, F3D_ERR_INVALID, "radius_graph: bad arguments");
+    *nnz = 0;
+    if (n == 0) { ctx->graph_n = 0; return F3D_OK; }
+    void *dxyz, *doffs;
+    if ((rc = ensure(ctx, SLOT_XYZ, xyz_bytes(dtype, n), &dxyz))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT1, (size_t)(n + 1) * 8, &doffs))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dxyz, xyz, xyz_bytes(dtype, n), hipMemcpyHostToDevice, s));
+    if ((rc = f3d_radius_graph_count_dev(ctx, dxyz, dtype, n, radius, (int64_t*)doffs, nnz, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(offsets, doffs, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+int f3d_radius_graph_fill(f3d_ctx* ctx, int64_t n, int32_t* nbrs) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n != ctx->graph_n || n < 0) return fail(ctx, F3D_ERR_INVALID, "radius_graph_fill: call f3d_radius_graph_count for this cloud first");
+    if (n == 0) return F3D_OK;
+    hipStream_t s = ctx->stream;
+    int64_t nnz = 0;
+    const int64_t* doffs = (const int64_t*)ctx->slot[SLOT_OUT1];           // left there by f3d_radius_graph_count
+    F3D_HIP(ctx, hipMemcpyAsync(&nnz, doffs + n, 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    if (nnz == 0) return F3D_OK;
+    if (!nbrs) return fail(ctx, F3D_ERR_INVALID, "radius_graph_fill: nbrs is NULL");
+    void* dnb;
+    if ((rc = ensure(ctx, SLOT_MASKS, (size_t)nnz * 4, &dnb))) return rc;
+    if ((rc = f3d_radius_graph_fill_dev(ctx, n, doffs, (int32_t*)dnb, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(nbrs, dnb, (size_t)nnz * 4, hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
     return F3D_OK;
 }

@@ -17,6 +17,13 @@ struct f3d_cellgrid {                      // device-resident description of the
     int ncells;                            // key space (last key: non-finite points)
 };
 
+struct f3d_graphgrid {                     // uniform grid of the radius graph (by-value kernel argument)
+    double lo[3];
+    double inv_cell;                       // 1 / cell edge; the edge is a hair above the query radius
+    int dim[3];
+    int pad;
+};
+
 struct f3d_plane_args {                    // by-value kernel argument of k_inside_polyhedra
     int m;
     int accumulate;                        // 1: AND into the existing `inside` bytes (chained launches)
@@ -61,6 +68,16 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
 // same-class connected components (f3d_cc.hip): root[i] = smallest index of i's component; parent = int32 [n] scratch
 hipError_t f3d_launch_components(const int64_t* classes, int64_t n, const int64_t* offs, const int32_t* nbrs, int32_t* parent,
                                  int64_t* root, int* err, hipStream_t s);
+// radius graph (f3d_graph.hip): KDTree.query_radius(points, r) as CSR.  bbox partials -> host picks the grid -> count pass
+// (offsets[n + 1], exclusive scan) -> fill pass; `scratch` (f3d_graph_scratch_bytes) carries the grid between the passes
+size_t f3d_graph_bbox_bytes(void);
+hipError_t f3d_launch_graph_bbox(const void* xyz, int dtype, int64_t n, void* partial, int* nblocks, hipStream_t s);
+int f3d_graph_reduce_bbox(const void* partial_host, int nblocks, double lo[3], double hi[3]);      // 1: non-finite coordinates seen
+size_t f3d_graph_scratch_bytes(int64_t n, int64_t ncells);
+hipError_t f3d_launch_graph_count(const void* xyz, int dtype, int64_t n, const f3d_graphgrid& g, double r2, void* scratch,
+                                  int64_t* offsets, hipStream_t s);
+hipError_t f3d_launch_graph_fill(int64_t n, const f3d_graphgrid& g, double r2, const void* scratch, const int64_t* offsets,
+                                 int32_t* nbrs, hipStream_t s);
 // a12: remaining intersections.py primitives (f3d_geom.hip), device pointers
 hipError_t f3d_launch_ray_x_lines(const double o[3], const double d[3], const double* starts, const double* ends, int64_t n, double* pts,
                                   uint8_t* within, hipStream_t s);

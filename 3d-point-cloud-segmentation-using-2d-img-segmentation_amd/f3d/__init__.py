@@ -100,6 +100,10 @@ def library():
         'f3d_lines_plane_projection': (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         'f3d_components_same_class': (i32, [vp, vp, i64, vp, vp, vp]),
         'f3d_components_same_class_dev': (i32, [vp, vp, i64, vp, vp, vp, vp, vp]),
+        'f3d_radius_graph_count': (i32, [vp, vp, i32, i64, dbl, vp, vp]),
+        'f3d_radius_graph_fill': (i32, [vp, i64, vp]),
+        'f3d_radius_graph_count_dev': (i32, [vp, vp, i32, i64, dbl, vp, vp, vp]),
+        'f3d_radius_graph_fill_dev': (i32, [vp, i64, vp, vp, vp]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
@@ -393,6 +397,16 @@ class Context:
         root = np.empty(len(cls), np.int64)
         self._check(self._lib.f3d_components_same_class(self._h, _ptr(cls), len(cls), _ptr(offs), _ptr(nb), _ptr(root)))
         return root
+
+    def radius_graph(self, points, radius):
+        """KDTree(points).query_radius(points, r=radius) (fusion.py:374-375) as CSR: (offsets int64 [n+1], neighbours int32)."""
+        p, dt = _xyz(points)
+        offs = np.zeros(len(p) + 1, np.int64)
+        nnz = C.c_int64(0)
+        self._check(self._lib.f3d_radius_graph_count(self._h, _ptr(p), dt, len(p), float(radius), _ptr(offs), C.byref(nnz)))
+        nb = np.empty(nnz.value, np.int32)
+        self._check(self._lib.f3d_radius_graph_fill(self._h, len(p), _ptr(nb)))
+        return offs, nb
 
     # ---------------------------------------------------------------- device-pointer calls
     def project_vote_argmax_dev(self, xyz_ptr, dtype, n, views_ptr, nviews, masks_ptr, h, w, nclasses, threshold,

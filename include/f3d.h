@@ -263,6 +263,23 @@ int f3d_components_same_class_dev(f3d_ctx* ctx, const int64_t* classes, int64_t 
                                   const int32_t* neighbours, int32_t* parent_scratch /*int32 [n]*/, int64_t* root,
                                   void* stream);
 
+/* ---- (f)#1: the adjacency itself, Fusion.save_data (Fusion3DSeg/fusion.py:374-375) -------- */
+/* tree = KDTree(points); adj = tree.query_radius(points, r=2*ds_radius): for every point the indices of all points
+ * (itself included) whose float64 squared distance ((dx*dx + dy*dy) + dz*dz, sklearn's euclidean_rdist order) is
+ * <= r*r.  Returned as CSR in two passes because the size is data dependent:
+ *   count: offsets int64 [n+1] (exclusive scan, offsets[n] = *nnz); the grid stays in the context,
+ *   fill : neighbours int32 [*nnz], row i = offsets[i] .. offsets[i+1]; must follow the count pass of the same cloud.
+ * Order inside a row: by grid cell, then ascending index (sklearn's tree-traversal order is unspecified as well;
+ * split_into_instances, the only consumer, does not depend on it).  NaN / infinite coordinates -> F3D_ERR_INVALID
+ * (sklearn raises ValueError).  The result is symmetric and feeds f3d_components_same_class directly. */
+int f3d_radius_graph_count(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, double radius,
+                           int64_t* offsets /*[n+1]*/, int64_t* nnz);
+int f3d_radius_graph_fill(f3d_ctx* ctx, int64_t n, int32_t* neighbours /*[nnz]*/);
+int f3d_radius_graph_count_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, double radius,
+                               int64_t* offsets /*device [n+1]*/, int64_t* nnz /*host*/, void* stream);
+int f3d_radius_graph_fill_dev(f3d_ctx* ctx, int64_t n, const int64_t* offsets /*device*/,
+                              int32_t* neighbours /*device [nnz]*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

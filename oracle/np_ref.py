@@ -403,6 +403,21 @@ def merge_bb(info_sem, ids, points, box_fn=obb_from_points):
 # ----------------------------------------------------------------------------
 # (f)#1  split_into_instances (segUtils/cv.py:402-500), literal restatement
 # ----------------------------------------------------------------------------
+def radius_adjacency(points, r):
+    """fusion.py:374-375: KDTree(points).query_radius(points, r) -- brute force over all pairs with the tree's leaf test:
+    sklearn's euclidean_rdist accumulates (x1[j] - x2[j])**2 for j = 0, 1, 2 in that order and query_radius keeps
+    rdist <= r**2 (sklearn/neighbors/_binary_tree.pxi, _dist_metrics.pyx; pinned against the installed sklearn by
+    tests/test_oracle_golden.py).  Rows are returned sorted; sklearn's own order is the traversal's."""
+    P = np.asarray(points, np.float64)
+    r2 = float(r) * float(r)
+    out = []
+    for i in range(len(P)):
+        t0, t1, t2 = P[i, 0] - P[:, 0], P[i, 1] - P[:, 1], P[i, 2] - P[:, 2]
+        d = (t0 * t0 + t1 * t1) + t2 * t2
+        out.append(np.nonzero(d <= r2)[0])
+    return out
+
+
 def split_into_instances(classes, adj, nclasses=133, instance_classes=None, minimum_points=1):
     """Flood fill from the lowest remaining index through same-class neighbours (directed neighbour lists, FIFO
     queue), clusters numbered in visit order, small ones folded into one bucket -- cv.py:425-500 line by line."""

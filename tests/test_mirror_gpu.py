@@ -279,6 +279,62 @@ def test_components_kernel_long_chains_and_bad_index():
         ctx.components_same_class(cls, offs, nb)
 
 
+def _rows(offs, nbrs):
+    return [np.sort(nbrs[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)]
+
+
+def test_radius_graph_matches_sklearn_kdtree():
+    """(f)#1 adjacency build (fusion.py:374-375) against the library the reference calls, ties at the radius included."""
+    from sklearn.neighbors import KDTree
+    ctx = f3d.default_context()
+    rng = np.random.default_rng(21)
+    lattice = np.stack(np.meshgrid(np.arange(9.), np.arange(7.), np.arange(5.), indexing='ij'), -1).reshape(-1, 3)
+    far = rng.uniform(0, 2, (3000, 3)) + np.array([1.0e6, -2.0e6, 3.0e5])           # cell indices from large coordinates
+    cases = [(synth.cloud(30_000), 0.1), (rng.uniform(-1, 1, (5000, 3)), 0.3), (lattice, 1.0), (lattice, np.sqrt(2.0)),
+             (lattice * 0.05, 2 * 0.05), (far, 0.08), (np.repeat(rng.uniform(0, 1, (300, 3)), 4, axis=0), 0.0),
+             (np.zeros((70, 3)), 0.5), (rng.uniform(0, 1, (1, 3)), 0.2), (rng.uniform(0, 1, (2, 3)), 5.0),
+             (rng.uniform(0, 100, (4000, 3)) * [1, 1, 0], 2.5)]
+    for P, r in cases:
+        offs, nbrs = ctx.radius_graph(P, r)
+        want = KDTree(P).query_radius(P, r=r)
+        assert offs[0] == 0 and offs[-1] == len(nbrs) == sum(len(w) for w in want), (len(P), r)
+        assert all(np.array_equal(np.sort(w), g) for w, g in zip(want, _rows(offs, nbrs))), (len(P), r)
+        brute = O.radius_adjacency(P[:400], r)                                        # the oracle agrees on what it can afford
+        if len(P) <= 400:
+            assert all(np.array_equal(b, g) for b, g in zip(brute, _rows(offs, nbrs)))
+    # float32 storage is widened exactly, as KDTree does
+    P32 = synth.cloud(8000, dtype=np.float32)
+    offs, nbrs = ctx.radius_graph(P32, 0.2)
+    want = KDTree(P32.astype(np.float64)).query_radius(P32.astype(np.float64), r=0.2)
+    assert all(np.array_equal(np.sort(w), g) for w, g in zip(want, _rows(offs, nbrs)))
+    offs, nbrs = ctx.radius_graph(np.zeros((0, 3)), 0.3)
+    assert offs.tolist() == [0] and len(nbrs) == 0
+    bad = synth.cloud(100); bad[7, 1] = np.nan
+    with pytest.raises(ValueError):                                                   # as sklearn: ValueError("Input contains NaN")
+        ctx.radius_graph(bad, 0.1)
+
+
+def test_radius_adjacency_feeds_split_into_instances():
+    """adj.pkl's content and the CSR short cut give the same instances as the reference's KDTree adjacency."""
+    from sklearn.neighbors import KDTree
+    from Fusion3DSeg.fusion import radius_adjacency
+    from Fusion3DSeg.segUtils.cv import split_into_instances
+    rng = np.random.default_rng(22)
+    P = rng.uniform(0, 6, (8000, 3)) * [1, 1, 0.1]
+    classes = rng.choice([86, 114, 115, 133], len(P), p=[0.35, 0.3, 0.2, 0.15]).astype(np.int64)
+    ds_radius = 0.06
+    adj_ref = KDTree(P).query_radius(P, r=2 * ds_radius)
+    adj = radius_adjacency(P, ds_radius)
+    assert adj.dtype == object and all(a.dtype == np.int64 for a in adj[:5])
+    assert all(np.array_equal(np.sort(a), np.sort(b)) for a, b in zip(adj, adj_ref))
+    assert radius_adjacency(P, None) is None
+    want = O.split_into_instances(classes, adj_ref, 133, [86, 114, 115], 5)
+    for a in (adj, radius_adjacency(P, ds_radius, as_csr=True)):
+        got = split_into_instances(classes, a, 133, [86, 114, 115], 5)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[3], want[3])
+        assert np.array_equal(_info_rows(got[2]), _info_rows(want[2]))
+
+
 def test_other_intersections_primitives_match_reference_golden(golden):
     import Fusion3DSeg.intersections as I
     g = golden('intersections')

@@ -151,3 +151,17 @@ def test_c_oracle_equals_numpy_oracle(golden):
         got, gvv = Cc.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
                                           133, thr, flt, return_votes=True)
         assert np.array_equal(got, want) and np.array_equal(gvv, wv)
+
+
+def test_radius_adjacency_restates_sklearn_kdtree():
+    """(f)#1: the oracle's pairwise test against the library the reference calls (sklearn KDTree, fusion.py:374-375),
+    including lattices whose neighbour distances equal the radius exactly."""
+    from sklearn.neighbors import KDTree
+    rng = np.random.default_rng(5)
+    lattice = np.stack(np.meshgrid(np.arange(7.), np.arange(6.), np.arange(4.), indexing='ij'), -1).reshape(-1, 3)
+    cases = [(rng.uniform(-1, 1, (600, 3)), 0.25), (lattice, 1.0), (lattice, np.sqrt(2.0)), (lattice * 0.1, 0.1),
+             (lattice * 0.05, 2 * 0.05), (np.repeat(rng.uniform(0, 1, (40, 3)), 3, axis=0), 0.0)]
+    for P, r in cases:
+        want = KDTree(P).query_radius(P, r=r)
+        got = O.radius_adjacency(P, r)
+        assert all(np.array_equal(np.sort(w), g) for w, g in zip(want, got)), r
