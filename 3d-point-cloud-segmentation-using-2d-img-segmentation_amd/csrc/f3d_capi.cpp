@@ -334,6 +334,39 @@ int f3d_rotate_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double q[4]
 }
 
 // ---------------------------------------------------------------------------------------------
+// (f)#3 depth frame -> world points
+// ---------------------------------------------------------------------------------------------
+static size_t depth_bytes(int depth_type, int64_t n) { return (size_t)n * (depth_type == F3D_DEPTH_U16 ? 2 : depth_type == F3D_DEPTH_F32 ? 4 : 8); }
+
+int f3d_unproject_depth_dev(f3d_ctx* ctx, const void* depth, int depth_type, int h, int w, const double K[9], double depth_scale,
+                            const double q_wxyz[4], const double t[3], double* xyz, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (h < 0 || w < 0 || !K || !q_wxyz || !t || (depth_type != F3D_DEPTH_U16 && depth_type != F3D_DEPTH_F32 && depth_type != F3D_DEPTH_F64) ||
+        ((int64_t)h * w > 0 && (!depth || !xyz)))
+        return fail(ctx, F3D_ERR_INVALID, "unproject_depth: bad arguments");
+    F3D_HIP(ctx, f3d_launch_unproject_depth(depth, depth_type, h, w, K, depth_scale, q_wxyz, t, xyz, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_unproject_depth(f3d_ctx* ctx, const void* depth, int depth_type, int h, int w, const double K[9], double depth_scale,
+                        const double q_wxyz[4], const double t[3], double* xyz) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t n = (int64_t)h * w;
+    if (h < 0 || w < 0 || (n > 0 && (!depth || !xyz))) return fail(ctx, F3D_ERR_INVALID, "unproject_depth: bad arguments");
+    if (depth_type != F3D_DEPTH_U16 && depth_type != F3D_DEPTH_F32 && depth_type != F3D_DEPTH_F64)
+        return fail(ctx, F3D_ERR_INVALID, "unproject_depth: unknown depth type %d", depth_type);
+    if (n == 0) return F3D_OK;
+    void *din, *dout;
+    if ((rc = ensure(ctx, SLOT_AUX0, depth_bytes(depth_type, n), &din))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 24, &dout))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(din, depth, depth_bytes(depth_type, n), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = f3d_unproject_depth_dev(ctx, din, depth_type, h, w, K, depth_scale, q_wxyz, t, (double*)dout, ctx->stream))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(xyz, dout, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    F3D_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // a2 / a4 / single-view fused
 // ---------------------------------------------------------------------------------------------
 int f3d_project_view_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* view, int32_t* uv,

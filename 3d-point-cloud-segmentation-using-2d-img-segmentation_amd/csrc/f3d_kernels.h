@@ -38,6 +38,8 @@ struct f3d_filter_args {                   // filter_classes of VotingSegmentati
 };
 
 hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], double* out, hipStream_t s);
+hipError_t f3d_launch_unproject_depth(const void* depth, int depth_type, int h, int w, const double K[9], double scale,
+                                      const double q[4], const double t[3], double* out, hipStream_t s);
 hipError_t f3d_launch_project_view(const void* xyz, int dtype, int64_t n, const f3d_view& vw, int32_t* uv, uint8_t* inside,
                                    hipStream_t s);
 hipError_t f3d_launch_inside_polyhedra(const void* xyz, int dtype, int64_t n, const f3d_plane_args& pa, uint8_t* inside,

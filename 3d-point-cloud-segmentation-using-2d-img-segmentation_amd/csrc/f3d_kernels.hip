@@ -38,6 +38,27 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_rotate(const double* __restrict__
     }
 }
 
+// (f)#3 depth frame -> world points: RTAB2Cache.__getRGBP3d (RTAB_utils/ios_rtab.py:171-173), the /1000 of __getModP3d (:187)
+// and its rotate + translate (:190-192), fused.  Streaming: 2-8 B in, 24 B out per pixel.
+struct unproject_arg { double fx, fy, cx, cy, scale, q[4], t[3]; };
+
+template <typename D>
+__global__ __launch_bounds__(F3D_BLOCK) void k_unproject_depth(const D* __restrict__ depth, int h, int w, unproject_arg a,
+                                                                double* __restrict__ out) {
+    const int64_t n = (int64_t)h * w;
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t row = i / w;
+        const double px = (double)(i - row * w), py = (double)row;      // np.linspace(0, W-1, W): the integers, exactly
+        const double d = (double)depth[i];
+        f3d_p3 c;
+        c.x = ((px - a.cx) * (d / a.fx)) / a.scale;                     // :171 then :187
+        c.y = ((py - a.cy) * (d / a.fy)) / a.scale;                     // :172
+        c.z = d / a.scale;                                              // :173
+        const f3d_p3 o = f3d_rotate(a.q, c);                            // :190-191
+        out[3 * i] = o.x + a.t[0]; out[3 * i + 1] = o.y + a.t[1]; out[3 * i + 2] = o.z + a.t[2];   // :192
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // a2 (+a4): one view, streaming.  24 B (f64) or 12 B (f32) in, 8 B uv + 1 B inside out per point.
 // The view record arrives in the kernarg segment -> SGPRs (wave-uniform).
@@ -842,6 +863,22 @@ hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], do
     if (n <= 0) return hipSuccess;
     quat_arg qa; for (int k = 0; k < 4; ++k) qa.q[k] = q[k];
     hipLaunchKernelGGL(k_rotate, dim3(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), dim3(F3D_BLOCK), 0, s, xyz, n, qa, out);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_unproject_depth(const void* depth, int depth_type, int h, int w, const double K[9], double scale,
+                                      const double q[4], const double t[3], double* out, hipStream_t s) {
+    const int64_t n = (int64_t)h * w;
+    if (n <= 0) return hipSuccess;
+    unproject_arg a;
+    a.fx = K[0]; a.fy = K[4]; a.cx = K[2]; a.cy = K[5]; a.scale = scale;
+    for (int k = 0; k < 4; ++k) a.q[k] = q[k];
+    for (int k = 0; k < 3; ++k) a.t[k] = t[k];
+    const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+    if (depth_type == F3D_DEPTH_U16) hipLaunchKernelGGL(k_unproject_depth<uint16_t>, g, b, 0, s, (const uint16_t*)depth, h, w, a, out);
+    else if (depth_type == F3D_DEPTH_F32) hipLaunchKernelGGL(k_unproject_depth<float>, g, b, 0, s, (const float*)depth, h, w, a, out);
+    else if (depth_type == F3D_DEPTH_F64) hipLaunchKernelGGL(k_unproject_depth<double>, g, b, 0, s, (const double*)depth, h, w, a, out);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -100,6 +100,8 @@ def library():
         'f3d_lines_plane_projection': (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         'f3d_components_same_class': (i32, [vp, vp, i64, vp, vp, vp]),
         'f3d_components_same_class_dev': (i32, [vp, vp, i64, vp, vp, vp, vp, vp]),
+        'f3d_unproject_depth': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp]),
+        'f3d_unproject_depth_dev': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp, vp]),
         'f3d_radius_graph_count': (i32, [vp, vp, i32, i64, dbl, vp, vp]),
         'f3d_radius_graph_fill': (i32, [vp, i64, vp]),
         'f3d_radius_graph_count_dev': (i32, [vp, vp, i32, i64, dbl, vp, vp, vp]),
@@ -397,6 +399,22 @@ class Context:
         root = np.empty(len(cls), np.int64)
         self._check(self._lib.f3d_components_same_class(self._h, _ptr(cls), len(cls), _ptr(offs), _ptr(nb), _ptr(root)))
         return root
+
+    def unproject_depth(self, depth, K, q_wxyz, t, depth_scale=1000.0):
+        """Depth frame [H,W] (uint16, float32 or float64) -> world points float64 [H*W,3] (ios_rtab.py:171-173,187-192)."""
+        d = np.ascontiguousarray(depth)
+        if d.ndim != 2:
+            raise ValueError('depth must be [H,W]')
+        if d.dtype == np.uint16:
+            code = 2
+        elif d.dtype == np.float32:
+            code = 1
+        else:
+            d, code = np.ascontiguousarray(d, dtype=np.float64), 0
+        K, q, t = _f64(K, (3, 3)), _f64(q_wxyz, (4,)), _f64(t, (3,))
+        out = np.empty((d.size, 3), np.float64)
+        self._check(self._lib.f3d_unproject_depth(self._h, _ptr(d), code, d.shape[0], d.shape[1], _ptr(K), float(depth_scale), _ptr(q), _ptr(t), _ptr(out)))
+        return out
 
     def radius_graph(self, points, radius):
         """KDTree(points).query_radius(points, r=radius) (fusion.py:374-375) as CSR: (offsets int64 [n+1], neighbours int32)."""

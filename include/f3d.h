@@ -280,6 +280,20 @@ int f3d_radius_graph_count_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, i
 int f3d_radius_graph_fill_dev(f3d_ctx* ctx, int64_t n, const int64_t* offsets /*device*/,
                               int32_t* neighbours /*device [nnz]*/, void* stream);
 
+/* ---- (f)#3: depth frame -> world points (RTAB_utils/ios_rtab.py) -------------------------- */
+/* RTAB2Cache.__getRGBP3d (:171-173): x = (px - cx) * (d / fx), y = (py - cy) * (d / fy), z = d with the scaled
+ * intrinsics K and the integer pixel grid; __getModP3d: divided by depth_scale (1000: mm -> m, :187), rotated by the
+ * frame's camera->world quaternion (w,x,y,z; the pose file stores x,y,z,w, :190) with SpatQuadranion.rotate and
+ * translated (:191-192).  depth [h,w] row-major -> xyz float64 [h*w,3], pixel order = row-major, every operation in
+ * the reference's order (float64, IEEE division). */
+#define F3D_DEPTH_U16 2          /* 16-bit PNG depth as PIL loads it */
+#define F3D_DEPTH_F32 1
+#define F3D_DEPTH_F64 0
+int f3d_unproject_depth(f3d_ctx* ctx, const void* depth, int depth_type, int h, int w, const double K[9],
+                        double depth_scale, const double q_wxyz[4], const double t[3], double* xyz /*[h*w*3]*/);
+int f3d_unproject_depth_dev(f3d_ctx* ctx, const void* depth, int depth_type, int h, int w, const double K[9],
+                            double depth_scale, const double q_wxyz[4], const double t[3], double* xyz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

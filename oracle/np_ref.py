@@ -403,6 +403,20 @@ def merge_bb(info_sem, ids, points, box_fn=obb_from_points):
 # ----------------------------------------------------------------------------
 # (f)#1  split_into_instances (segUtils/cv.py:402-500), literal restatement
 # ----------------------------------------------------------------------------
+def unproject_depth(depth, K, q_wxyz, t, depth_scale=1000):
+    """RTAB2Cache.__getRGBP3d (RTAB_utils/ios_rtab.py:167-173) for one frame, then __getModP3d (:187-192): the NumPy
+    expressions of those lines with the pinned ``rotate`` (a1) in place of SpatQuadranion.rotate.  No third-party
+    arithmetic on this path; the file-reading around it (PIL, skimage.resize for the colours) is out of scope."""
+    d = np.asarray(depth)
+    H, W = d.shape
+    px, py = np.meshgrid(np.linspace(0, W - 1, W), np.linspace(0, H - 1, H))              # :167-168
+    cx = np.multiply(px - K[0, 2], d / K[0, 0])                                           # :171
+    cy = np.multiply(py - K[1, 2], d / K[1, 1])                                           # :172
+    pts = np.array([cx, cy, d]).transpose(1, 2, 0).reshape(-1, 3)                         # :173
+    pts = np.divide(pts, depth_scale)                                                     # :187
+    return rotate(q_wxyz, pts) + np.asarray(t, np.float64)                                # :190-192
+
+
 def radius_adjacency(points, r):
     """fusion.py:374-375: KDTree(points).query_radius(points, r) -- brute force over all pairs with the tree's leaf test:
     sklearn's euclidean_rdist accumulates (x1[j] - x2[j])**2 for j = 0, 1, 2 in that order and query_radius keeps

@@ -335,6 +335,23 @@ def test_radius_adjacency_feeds_split_into_instances():
         assert np.array_equal(_info_rows(got[2]), _info_rows(want[2]))
 
 
+def test_unproject_depth_matches_oracle_bit_for_bit():
+    """(f)#3: ios_rtab.py:171-173,187-192 -- every depth storage type, an odd-sized frame, an un-normalised pose quaternion."""
+    from RTAB_utils.ios_rtab import frame_points_world, resize_camera_matrix
+    rng = np.random.default_rng(31)
+    K = resize_camera_matrix(synth.CALIB_K, 256 / 1440, 192 / 1920)
+    for (h, w) in [(192, 256), (37, 53), (1, 1)]:
+        d16 = rng.integers(0, 6000, (h, w)).astype(np.uint16)
+        d16[0, 0] = 0                                                       # holes stay at the camera centre
+        for depth in (d16, d16.astype(np.float32) * np.float32(1.1), d16.astype(np.float64) * 0.93, d16.astype(np.int32)):
+            q_xyzw = rng.normal(size=4) * 1.3
+            t = rng.normal(size=3)
+            want = O.unproject_depth(depth, K, q_xyzw[[3, 0, 1, 2]], t)
+            got = frame_points_world(depth, K, q_xyzw, t)
+            assert got.shape == (h * w, 3) and np.array_equal(got, want), (h, w, depth.dtype)
+    assert f3d.default_context().unproject_depth(np.zeros((0, 5), np.uint16), K, [1, 0, 0, 0], [0, 0, 0]).shape == (0, 3)
+
+
 def test_other_intersections_primitives_match_reference_golden(golden):
     import Fusion3DSeg.intersections as I
     g = golden('intersections')
