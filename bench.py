@@ -298,6 +298,16 @@ def main():
             b = (xyz_b + 1) * n
             extras['inside_polyhedra (a4, 5 planes)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
                                                              bytes_per_point=xyz_b + 1)
+        # (f)#3: one 1024x1024 16-bit depth frame -> world points
+        dep = torch.randint(0, 6000, (S, S), device=dev, dtype=torch.int32).to(torch.uint16)
+        wpts = torch.empty((S * S, 3), dtype=torch.float64, device=dev)
+        Kd = np.ascontiguousarray(K, dtype=np.float64); qd = np.array([0.5, 0.5, -0.5, 0.5]); td = np.array([0.25, -0.5, 1.0])
+        tk = time_kernel(torch, lambda: ctx._check(ctx._lib.f3d_unproject_depth_dev(ctx._h, dep.data_ptr(), 2, S, S, Kd.ctypes.data, 1000.0, qd.ctypes.data,
+                                                                                    td.ctypes.data, wpts.data_ptr(), stream.cuda_stream)), 10, stream)
+        b = 26 * S * S
+        extras['unproject_depth ((f)#3, 1024x1024 u16 frame)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                                                       bytes_per_pixel=26)
+        del dep, wpts
         # a10/a11: all points x 64 oriented boxes, membership co-occurrence only
         boxes = np.zeros((64, 15)); boxes[:, 0:3] = rng.uniform([-5, -5, 0], [5, 5, 3], (64, 3))
         boxes[:, 3:12] = np.eye(3).reshape(-1); boxes[:, 12:15] = 0.8
