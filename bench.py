@@ -299,7 +299,7 @@ def main():
             extras['inside_polyhedra (a4, 5 planes)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
                                                              bytes_per_point=xyz_b + 1)
         # (f)#3: one 1024x1024 16-bit depth frame -> world points
-        dep = torch.randint(0, 6000, (S, S), device=dev, dtype=torch.int32).to(torch.uint16)
+        dep = torch.randint(0, 6000, (S, S), device=dev, dtype=torch.int16)       # < 32768: the same bits as uint16
         wpts = torch.empty((S * S, 3), dtype=torch.float64, device=dev)
         Kd = np.ascontiguousarray(K, dtype=np.float64); qd = np.array([0.5, 0.5, -0.5, 0.5]); td = np.array([0.25, -0.5, 1.0])
         tk = time_kernel(torch, lambda: ctx._check(ctx._lib.f3d_unproject_depth_dev(ctx._h, dep.data_ptr(), 2, S, S, Kd.ctypes.data, 1000.0, qd.ctypes.data,
