@@ -134,16 +134,35 @@ template <> struct hist_traits<MODE_HIST16> { static constexpr int per_word = 2,
 #define F3D_CULL_ROW 23                       // floats per view in the LDS cull table (22 used, odd stride = no bank conflicts)
 #define F3D_FAST_EPS 1.1368683772161603e-13   // 2^-43
 
+// float32 cull planes of one view, copied by value (wave-uniform -> scalar loads -> SGPRs); see load_proj / pin below
+struct cull_consts { float n[F3D_NPLANES][3]; float off[F3D_NPLANES]; float rel, abs; };
+__device__ __forceinline__ cull_consts load_cull(const f3d_view& vw) {
+    cull_consts cc;
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        cc.n[m][0] = vw.cull_n32[m][0]; cc.n[m][1] = vw.cull_n32[m][1]; cc.n[m][2] = vw.cull_n32[m][2]; cc.off[m] = vw.cull_off32[m];
+    }
+    cc.rel = vw.cull_rel32; cc.abs = vw.cull_abs32;
+    return cc;
+}
+__device__ __forceinline__ void pin(cull_consts& cc) {
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        asm volatile("" : "+s"(cc.n[m][0])); asm volatile("" : "+s"(cc.n[m][1])); asm volatile("" : "+s"(cc.n[m][2])); asm volatile("" : "+s"(cc.off[m]));
+    }
+    asm volatile("" : "+s"(cc.rel)); asm volatile("" : "+s"(cc.abs));
+}
+
 // per-point float32 cull against one view (SGPR-resident record): maybe = not surely outside, sure = surely inside
-__device__ __forceinline__ void cull_point32(const f3d_view& vw, float px, float py, float pz, float ps, bool small,
+__device__ __forceinline__ void cull_point32(const cull_consts& vw, float px, float py, float pz, float ps, bool small,
                                              bool& maybe, bool& sure) {
-    const float marg = __builtin_fmaf(vw.cull_rel32, ps, vw.cull_abs32);
+    const float marg = __builtin_fmaf(vw.rel, ps, vw.abs);
     bool mb = true, sr = true;
 #pragma unroll
     for (int m = 0; m < F3D_NPLANES; ++m) {
-        const float a = __builtin_fmaf(vw.cull_n32[m][0], px,
-                        __builtin_fmaf(vw.cull_n32[m][1], py,
-                        __builtin_fmaf(vw.cull_n32[m][2], pz, -vw.cull_off32[m])));
+        const float a = __builtin_fmaf(vw.n[m][0], px,
+                        __builtin_fmaf(vw.n[m][1], py,
+                        __builtin_fmaf(vw.n[m][2], pz, -vw.off[m])));
         mb = mb & (a > -marg);
         sr = sr & (a > marg);
     }
@@ -213,22 +232,55 @@ __device__ __forceinline__ void cull_point64(const f3d_view& vw, f3d_p3 p, doubl
     maybe = mb; sure = sr;
 }
 
+// The per-view constants of the fast projection, copied by value: wave-uniform, so they are scalar loads into SGPRs, and
+// copying them BEFORE the arithmetic that may or may not need them (the cull of a mixed view, the other view of a batch)
+// leaves one scalar-memory round trip exposed instead of one per use.
+struct proj_consts { double M[9]; double t[3]; };
+__device__ __forceinline__ proj_consts load_proj(const f3d_view& vw) {
+    proj_consts pc;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pc.M[k] = vw.M[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pc.t[k] = vw.t[k];
+    return pc;
+}
+// pin(): the copies exist in SGPRs at this point of the program.  Without it the compiler sinks each load next to its first
+// use (behind the cull of a mixed view, behind the other view's arithmetic of a batch) and the scalar-memory latency is
+// paid once per use; with all loads of an iteration requested first and pinned together it is paid once.
+__device__ __forceinline__ void pin(proj_consts& pc) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) asm volatile("" : "+s"(pc.M[k]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) asm volatile("" : "+s"(pc.t[k]));
+}
+
+// c1 of the bound below for one view, and 2^-43 times its maximum over all views of the launch (a larger bound only
+// defers a few more points): computed once per block, lanes over views
+__device__ __forceinline__ double view_c1(const f3d_view& vw, double umax) { return __builtin_fma(umax, vw.mnorm[2], fmax(vw.mnorm[0], vw.mnorm[1])); }
+__device__ __forceinline__ double launch_ec1(const f3d_view* __restrict__ views, int nviews, double umax, int lane) {
+    double c = 0.0;
+    for (int v = lane; v < nviews; v += 64) c = fmax(c, view_c1(views[v], umax));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c = fmax(c, __shfl_xor(c, off, 64));
+    return F3D_FAST_EPS * c;
+}
+
 // fast projection (C).  Returns true when (iu, iv) are proven equal to the canonical floor(u), floor(v) AND lie inside
 // the W x H image; `unsure` is set when the canonical arithmetic has to decide.  umax >= max(W, H): for |u| <= umax
-// the bound is rigorous; beyond it both paths are out of the image anyway.
-__device__ __forceinline__ bool project_fast(const f3d_view& vw, f3d_p3 p, int W, int H, double umax, int& iu, int& iv, bool& unsure) {
-    const double d0 = p.x - vw.t[0], d1 = p.y - vw.t[1], d2 = p.z - vw.t[2];
-    const double h0 = __builtin_fma(vw.M[0], d0, __builtin_fma(vw.M[1], d1, vw.M[2] * d2));
-    const double h1 = __builtin_fma(vw.M[3], d0, __builtin_fma(vw.M[4], d1, vw.M[5] * d2));
-    const double h2 = __builtin_fma(vw.M[6], d0, __builtin_fma(vw.M[7], d1, vw.M[8] * d2));
+// the bound is rigorous; beyond it both paths are out of the image anyway.  ec1 = 2^-43 c1, eumax = 2^-43 umax.
+__device__ __forceinline__ bool project_fast(const proj_consts& pc, double ec1, double eumax, f3d_p3 p, int W, int H, int& iu, int& iv,
+                                             bool& unsure) {
+    const double d0 = p.x - pc.t[0], d1 = p.y - pc.t[1], d2 = p.z - pc.t[2];
+    const double h0 = __builtin_fma(pc.M[0], d0, __builtin_fma(pc.M[1], d1, pc.M[2] * d2));
+    const double h1 = __builtin_fma(pc.M[3], d0, __builtin_fma(pc.M[4], d1, pc.M[5] * d2));
+    const double h2 = __builtin_fma(pc.M[6], d0, __builtin_fma(pc.M[7], d1, pc.M[8] * d2));
     double r = __builtin_amdgcn_rcp(h2);
     r = __builtin_fma(__builtin_fma(-h2, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-h2, r, 1.0), r, r);
     const double uf = h0 * r, vf = h1 * r;
     const double fu = floor(uf), fv = floor(vf);
-    // |fast - canonical| <= 2^-43 * (|d|_1 |r| (mnorm_k + |u| mnorm_2) + |u|), evaluated with |u| <= umax (wave-uniform part in SGPRs)
-    const double c1 = __builtin_fma(umax, vw.mnorm[2], fmax(vw.mnorm[0], vw.mnorm[1]));
-    const double b = __builtin_fma((F3D_FAST_EPS * ((fabs(d0) + fabs(d1)) + fabs(d2))) * fabs(r), c1, F3D_FAST_EPS * umax);
+    // |fast - canonical| <= 2^-43 * (|d|_1 |r| (mnorm_k + |u| mnorm_2) + |u|), evaluated with |u| <= umax
+    const double b = __builtin_fma(((fabs(d0) + fabs(d1)) + fabs(d2)) * fabs(r), ec1, eumax);
     // frac in (b, 1-b)  <=>  |frac - 0.5| < 0.5 - b      (NaN / inf -> false)
     const bool safe = (fabs((uf - fu) - 0.5) < 0.5 - b) && (fabs((vf - fv) - 0.5) < 0.5 - b);
     unsure = !safe;
@@ -406,6 +458,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         }
     };
     if (ngroups == 1) { stage_group(0); __syncthreads(); }
+    const double ec1 = launch_ec1(views, nviews, umax, lane), eumax = F3D_FAST_EPS * umax;
 
     // XCD-aware tile mapping: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so XCD x walks the
     // contiguous tile range [x*q, (x+1)*q): with a cell-sorted cloud that is one compact region of space, whose pixels
@@ -476,20 +529,25 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
             unsigned long long todo_v = valid_m & ~out_m & in_m;
             while (todo_v) {
                 int cv[F3D_CHUNK]; unsigned coff[F3D_CHUNK];
+                bool use[F3D_CHUNK];
+                proj_consts pc[F3D_CHUNK];
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) {       // the batch's scalar loads go out together
+                    use[k] = todo_v != 0ull;
+                    const int bit = use[k] ? __builtin_ctzll(todo_v) : 0;
+                    if (use[k]) todo_v &= todo_v - 1ull;
+                    cv[k] = 64 * g + bit;                    // an unused slot re-reads a valid record and gathers "no sample"
+                    pc[k] = load_proj(views[cv[k]]);
+                }
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) pin(pc[k]);
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) {
-                    cv[k] = 0; coff[k] = none_off;
-                    if (todo_v) {
-                        const int bit = __builtin_ctzll(todo_v);
-                        todo_v &= todo_v - 1ull;
-                        const int v = 64 * g + bit;
-                        const f3d_view& vw = views[v];
-                        int iu, iv;
-                        bool unsure;
-                        const bool hit = project_fast(vw, p, W, H, umax, iu, iv, unsure) & live & small;
-                        defer = defer | (unsure & live);
-                        cv[k] = v; coff[k] = hit ? mask_offset<true>(iu, iv, wt) : none_off;
-                    }
+                    int iu, iv;
+                    bool unsure;
+                    const bool hit = project_fast(pc[k], ec1, eumax, p, W, H, iu, iv, unsure) & live & small & use[k];
+                    defer = defer | (unsure & live & use[k]);
+                    coff[k] = hit ? mask_offset<true>(iu, iv, wt) : none_off;
                 }
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) vote_coded<MODE>(st, hist, tid, ccode[k]);
@@ -505,8 +563,11 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 todo_v &= todo_v - 1ull;
                 const int v = 64 * g + bit;
                 const f3d_view& vw = views[v];
+                cull_consts cc = load_cull(vw);
+                proj_consts pc = load_proj(vw);            // requested with the cull planes, not after the cull
+                pin(cc); pin(pc);
                 bool maybe, sure;
-                cull_point32(vw, px32, py32, pz32, ps32, small, maybe, sure);
+                cull_point32(cc, px32, py32, pz32, ps32, small, maybe, sure);
                 bool inside = live & small & sure;
                 const bool unc = live & small & maybe & !sure;
                 if (__any(unc)) {                           // inside the float32 margin: decide with float64 FMAs
@@ -521,7 +582,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                 int iu = 0, iv = 0;
                 if (inside) {
                     bool unsure;
-                    hit = project_fast(vw, p, W, H, umax, iu, iv, unsure);
+                    hit = project_fast(pc, ec1, eumax, p, W, H, iu, iv, unsure);
                     defer = defer | unsure;
                 }
                 vote_coded<MODE>(st, hist, tid, pend_code);
@@ -596,7 +657,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fastpath_audit(const T* __restric
             const f3d_view& vw = views[v];
             const bool in_exact = f3d_inside_view(vw, p);
             bool maybe, sure;
-            cull_point32(vw, (float)p.x, (float)p.y, (float)p.z, (float)pscale, small, maybe, sure);
+            cull_point32(load_cull(vw), (float)p.x, (float)p.y, (float)p.z, (float)pscale, small, maybe, sure);
             if ((sure && !in_exact) || (!maybe && in_exact)) ++cullwrong;
             if (!in_exact) continue;
             ++pairs;
@@ -605,7 +666,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fastpath_audit(const T* __restric
             project_exact(vw, p, eu, ev);
             for (int dim = 1024; dim >= 16; dim >>= 6) {
                 int iu, iv; bool unsure;
-                const bool hit = project_fast(vw, p, dim, dim, (double)dim, iu, iv, unsure);
+                const bool hit = project_fast(load_proj(vw), F3D_FAST_EPS * view_c1(vw, (double)dim), F3D_FAST_EPS * (double)dim, p, dim, dim, iu, iv, unsure);
                 const bool ehit = (eu >= 0.0) & (eu < (double)dim) & (ev >= 0.0) & (ev < (double)dim);
                 if (unsure) { if (dim == 1024) ++fallback; }
                 else if (hit != ehit || (hit && !((double)iu == eu && (double)iv == ev))) ++wrong;
