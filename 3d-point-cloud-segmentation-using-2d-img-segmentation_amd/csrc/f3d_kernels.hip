@@ -421,6 +421,28 @@ __device__ __forceinline__ bool finish_coded(const coded_state& st, const uint32
     return coded_count<MODE>(hist, tid, F3D_CODE_BAD) != 0u;
 }
 
+// Wave-wide min / max of a float through DPP (no LDS traffic, no s_waitcnt): xor-1 and xor-2 inside quads, mirror the half
+// rows and the rows (every lane of a 16-lane row then holds the row's result), row_bcast15 / row_bcast31 carry it across the
+// rows into lane 63, which is read back as a scalar.  6 VALU + 1 v_readlane per value; the __shfl_xor butterfly it replaces
+// was 6 ds_bpermute (LDS crossbar, each with its wait) + 6 VALU.  Inputs are never NaN (+-inf for lanes without a point).
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+    // written as one asm block: the compiler's own lowering of update_dpp + fminf spends 4 VALU per step (copy, v_mov_dpp,
+    // canonicalise, min); v_min/v_max take the DPP operand directly.  s_nop 1 = the 2 wait states a DPP read needs after
+    // a VALU write of the same register.  Must be called with all 64 lanes active.
+#define F3D_DPP_CHAIN(op)                                                                  \
+    asm volatile("s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+                 "s_nop 1" : "+v"(v))
+    if (MAX) F3D_DPP_CHAIN("v_max_f32_dpp"); else F3D_DPP_CHAIN("v_min_f32_dpp");
+#undef F3D_DPP_CHAIN
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // ------------------------------------------------------------------------------------------
 // k_fuse: the fast kernel.  It contains NO exact arithmetic: a point for which any accelerator cannot prove its
 // decision (a plane within the float32 margin, a pixel within the fast-projection bound of an integer, huge or
@@ -482,12 +504,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         // ---- (A) bounding box of this wave's live, well-behaved points
         float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
         if (live & small) { lo0 = hi0 = px32; lo1 = hi1 = py32; lo2 = hi2 = pz32; }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            lo0 = fminf(lo0, __shfl_xor(lo0, off, 64)); hi0 = fmaxf(hi0, __shfl_xor(hi0, off, 64));
-            lo1 = fminf(lo1, __shfl_xor(lo1, off, 64)); hi1 = fmaxf(hi1, __shfl_xor(hi1, off, 64));
-            lo2 = fminf(lo2, __shfl_xor(lo2, off, 64)); hi2 = fmaxf(hi2, __shfl_xor(hi2, off, 64));
-        }
+        lo0 = wave_reduce<false>(lo0); hi0 = wave_reduce<true>(hi0);
+        lo1 = wave_reduce<false>(lo1); hi1 = wave_reduce<true>(hi1);
+        lo2 = wave_reduce<false>(lo2); hi2 = wave_reduce<true>(hi2);
         const bool wave_any = __any(live & small);
         const float c0 = 0.5f * (lo0 + hi0), c1 = 0.5f * (lo1 + hi1), c2 = 0.5f * (lo2 + hi2);
         const float e0 = 0.5f * (hi0 - lo0) * 1.000002f + 1e-30f, e1 = 0.5f * (hi1 - lo1) * 1.000002f + 1e-30f,
