@@ -488,14 +488,34 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
     // Placement affects speed only, never results.
     const int64_t tiles_per_xcd = (ntiles + 7) / 8;
     const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = gridDim.x >> 3;
+    // Two-deep software pipeline over this block's tiles: perm[] of tile k+2 and xyz of tile k+1 are requested at the top of
+    // tile k.  With the in-step sort the point of a lane is xyz[perm[i]], a random 24-B read that nothing else overlaps.
+    auto tile_index = [&](int64_t jj) -> int64_t {          // first point index of this thread in tile jj of the block's walk, or -1
+        if (jj >= tiles_per_xcd) return -1;
+        const int64_t t = (int64_t)xcd * tiles_per_xcd + jj;
+        if (t >= ntiles) return -1;
+        const int64_t ii = t * F3D_BLOCK + tid;
+        return ii < n ? ii : -1;
+    };
+    auto fetch_orig = [&](int64_t ii) -> int64_t { return ii < 0 ? -1 : (perm ? (int64_t)perm[ii] : ii); };
+    auto fetch_point = [&](int64_t ii, int64_t oo) -> f3d_p3 {
+        f3d_p3 q = {0.0, 0.0, 0.0};
+        if (ii >= 0) q = load_point(xyz, gather_xyz ? oo : ii);
+        return q;
+    };
+    int64_t orig_n1 = fetch_orig(tile_index(bx));
+    f3d_p3 p_n1 = fetch_point(tile_index(bx), orig_n1);
+    int64_t orig_n2 = fetch_orig(tile_index(bx + gx));
     for (int64_t j = bx; j < tiles_per_xcd; j += gx) {
         const int64_t tile = (int64_t)xcd * tiles_per_xcd + j;
         if (tile >= ntiles) break;
         const int64_t i = tile * F3D_BLOCK + tid;
         const bool live = i < n;
-        f3d_p3 p = {0.0, 0.0, 0.0};
-        const int64_t orig = (live && perm) ? (int64_t)perm[i] : i;               // caller-order index of this point
-        if (live) p = load_point(xyz, gather_xyz ? orig : i);
+        const f3d_p3 p = p_n1;
+        const int64_t orig = live ? orig_n1 : i;                                  // caller-order index of this point
+        orig_n1 = orig_n2;
+        p_n1 = fetch_point(tile_index(j + gx), orig_n1);
+        orig_n2 = fetch_orig(tile_index(j + 2 * gx));
         const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
         const float px32 = (float)p.x, py32 = (float)p.y, pz32 = (float)p.z, ps32 = (float)pscale;
         const bool small = pscale < 1.0e30;                // float32 culls are meaningful (no overflow, no NaN)
