@@ -352,6 +352,16 @@ def test_unproject_depth_matches_oracle_bit_for_bit():
     assert f3d.default_context().unproject_depth(np.zeros((0, 5), np.uint16), K, [1, 0, 0, 0], [0, 0, 0]).shape == (0, 3)
 
 
+def test_unproject_depth_matches_reference_golden(golden):
+    """(f)#3 against the reference's own __getModP3d output (tests/golden/make_golden_rtab.py)."""
+    from RTAB_utils.ios_rtab import frames_points_world
+    g = golden('modp3d')
+    got = frames_points_world(g['depths'], g['K'], g['odo_xyzw'], g['odo_xyz'])
+    for q, t, orig, have, want in zip(g['odo_xyzw'], g['odo_xyz'], g['orig_ptx'], got, g['mod_ptx']):
+        scale = np.dot(q, q) * np.abs(orig / 1000).max() + np.abs(t).max()
+        assert np.abs(have - want).max() <= 8 * np.finfo(float).eps * scale
+
+
 def test_other_intersections_primitives_match_reference_golden(golden):
     import Fusion3DSeg.intersections as I
     g = golden('intersections')

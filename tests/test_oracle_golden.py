@@ -165,3 +165,14 @@ def test_radius_adjacency_restates_sklearn_kdtree():
         want = KDTree(P).query_radius(P, r=r)
         got = O.radius_adjacency(P, r)
         assert all(np.array_equal(np.sort(w), g) for w, g in zip(want, got)), r
+
+
+def test_unproject_depth_matches_reference_getModP3d(golden):
+    """(f)#3: oracle vs the reference's RTAB2Cache.__getModP3d (ios_rtab.py:179-193) on camera points produced by the restated
+    :171-173; tolerance = the rotate golden's (the reference's np.dot / np.cross go through BLAS)."""
+    g = golden('modp3d')
+    for d, q, t, orig, want in zip(g['depths'], g['odo_xyzw'], g['odo_xyz'], g['orig_ptx'], g['mod_ptx']):
+        assert np.array_equal(O.unproject_depth(d, g['K'], [1.0, 0, 0, 0], np.zeros(3), depth_scale=1), orig)
+        got = O.unproject_depth(d, g['K'], q[[3, 0, 1, 2]], t)
+        scale = np.dot(q, q) * np.abs(orig / 1000).max() + np.abs(t).max()
+        assert np.abs(got - want).max() <= 8 * np.finfo(float).eps * scale
