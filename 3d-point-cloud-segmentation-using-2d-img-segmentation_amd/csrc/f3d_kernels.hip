@@ -450,7 +450,7 @@ __device__ __forceinline__ float wave_reduce(float v) {
 // right behind, recomputes that point entirely with the reference's arithmetic (about 1e-3 of the points of a
 // random cloud).  Keeping the canonical sequences out of this kernel is what keeps its register budget small.
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE, bool WRITE_VOTES>
+template <typename T, bool WRITE_VOTES>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
                                                      const uint8_t* __restrict__ cmasks, int H, int W,
@@ -458,6 +458,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
                                                      int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
                                                      int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
                                                      unsigned int* __restrict__ todo_count, int32_t* __restrict__ todo) {
+    // 8-bit bins whatever the number of views: a bin that reaches 255 shows up in the running maximum (count field 255 = a
+    // vote that found the bin full) and sends the point to k_fuse_exact, which counts in 16 bits when V > 255
+    constexpr int MODE = MODE_HIST8;
     using HT = hist_traits<MODE>;
     extern __shared__ uint32_t lds_u32[];
     float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes of one view group
@@ -629,6 +632,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
             }
         }
         vote_coded<MODE>(st, hist, tid, pend_code);
+        defer = defer | (live & ((st.best >> 16) >= 0xFFu));                               // an 8-bit bin overflowed (needs > 255 views)
         if (defer) todo[atomicAdd(todo_count, 1u)] = (int32_t)(gather_xyz ? orig : i);     // index into xyz as this launch sees it
         const bool bad = finish_coded<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live & !defer, orig, classes, votes_out);
         if (bad & !defer) atomicOr(err, F3D_DEVERR_INDEX);
@@ -1024,10 +1028,10 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
                            double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
                            unsigned int* todo_count, int32_t* todo, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);
-    const size_t lds = f3d_fuse_lds_bytes(mode, nclasses);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const size_t lds_exact = lds - 64 * F3D_CULL_ROW * sizeof(float);
+    const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);      // bins of the exact kernel; the fast one uses 8 bits
+    const size_t lds = f3d_fuse_lds_bytes(MODE_HIST8, nclasses);
+    const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses) - 64 * F3D_CULL_ROW * sizeof(float);
+    if (lds > 160 * 1024 || lds_exact > 160 * 1024) return hipErrorInvalidValue;
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
     int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID);
     grid = (grid + 7) & ~7;                                  // the XCD-aware tile mapping needs a multiple of 8 blocks
@@ -1039,12 +1043,11 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     }
 #define F3D_FUSE(T, M, V)                                                                                      \
     do {                                                                                                       \
-        if (lds > 64 * 1024) {                                                                                 \
-            (void)hipFuncSetAttribute((const void*)k_fuse<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_fuse<T, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds_exact > 64 * 1024)                                                                             \
             (void)hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact); \
-        }                                                                                                      \
         if (fast)                                                                                              \
-            hipLaunchKernelGGL((k_fuse<T, M, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, \
+            hipLaunchKernelGGL((k_fuse<T, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, \
                                nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo); \
         hipLaunchKernelGGL((k_fuse_exact<T, M, V>), ge, b, lds_exact, s, (const T*)xyz, n, todo_count, fast ? todo : nullptr, \
                            views_dev, nviews, masks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0); \
