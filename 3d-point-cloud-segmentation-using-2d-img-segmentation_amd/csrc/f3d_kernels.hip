@@ -827,8 +827,13 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_vote_uv2pt(const int32_t* __restr
 // s = sum exp(x - m) (rescaled when the maximum moves), so the logits are read exactly once.  max prob = 1 / s.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sem_update(float x, int c, float& m, int& mi, float& s) {
-    if (x > m) { s = s * __expf(m - x) + 1.0f; m = x; mi = c; }
-    else s += __expf(x - m);
+    // one exponential per logit: exp(-|x - m|) is the rescale factor when the maximum moves and the new term when it does not
+    const float d = x - m;
+    const float e = __expf(-fabsf(d));
+    const bool up = d > 0.0f;                                    // first maximum wins (strict), NaN never does
+    s = up ? s * e + 1.0f : s + e;
+    m = up ? x : m;
+    mi = up ? c : mi;
 }
 
 template <bool VEC4>
