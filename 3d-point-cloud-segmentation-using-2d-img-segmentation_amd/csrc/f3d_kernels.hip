@@ -876,15 +876,29 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_sem_to_mask(const float* __restri
 // ("the two index lists share a point", merge_intersecting_bb.py:64-66,88-90): only points that
 // lie in at least one box do any pair work, and cooc bytes are written once (benign same-value race).
 // ------------------------------------------------------------------------------------------
-#define F3D_OBB_CHUNK 64
+struct obb_consts { double c[3], R[9], e[3]; };
+__device__ __forceinline__ obb_consts load_obb(const f3d_obb& b) {
+    obb_consts o;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.c[k] = b.center[k]; o.e[k] = b.extent[k]; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o.R[k] = b.R[k];
+    return o;
+}
+__device__ __forceinline__ void pin(obb_consts& o) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { asm volatile("" : "+s"(o.c[k])); asm volatile("" : "+s"(o.e[k])); }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) asm volatile("" : "+s"(o.R[k]));
+}
+
 template <typename T>
 __global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb(const T* __restrict__ xyz, int64_t n,
                                                               const f3d_obb* __restrict__ boxes, int B,
                                                               uint32_t* __restrict__ bits, uint8_t* __restrict__ cooc) {
-    extern __shared__ uint32_t obb_lds[];                   // [words][F3D_BLOCK] bitset, then the box chunk
+    extern __shared__ uint32_t obb_lds[];                   // [words][F3D_BLOCK] bitset of this tile's points
     const int words = (B + 31) >> 5;
     uint32_t* myb = obb_lds;
-    f3d_obb* sb = reinterpret_cast<f3d_obb*>(obb_lds + (size_t)words * F3D_BLOCK);
     const int tid = threadIdx.x;
     const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -893,33 +907,32 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb(const T* __restrict
         f3d_p3 p = {0, 0, 0};
         if (live) p = load_point(xyz, i);
         uint32_t any = 0;
-        for (int b0 = 0; b0 < B; b0 += F3D_OBB_CHUNK) {
-            const int nb = min(F3D_OBB_CHUNK, B - b0);
-            __syncthreads();
-            {
-                const double* src = reinterpret_cast<const double*>(boxes + b0);
-                double* dst = reinterpret_cast<double*>(sb);
-                for (int k = tid; k < nb * (int)(sizeof(f3d_obb) / 8); k += F3D_BLOCK) dst[k] = src[k];
-            }
-            __syncthreads();
-            for (int w0 = 0; w0 < nb; w0 += 32) {
-                uint32_t word = 0;
-                const int lim = min(32, nb - w0);
-                for (int k = 0; k < lim; ++k) {
-                    const f3d_obb& bx = sb[w0 + k];
-                    const double d0 = p.x - bx.center[0], d1 = p.y - bx.center[1], d2 = p.z - bx.center[2];
-                    bool in = live;
+        // the boxes are wave-uniform: scalar loads straight from global memory (SGPR operands).  Staging them in LDS made the
+        // kernel LDS-bound (15 broadcast 8-B reads per point-box test against ~25 VALU instructions); two boxes are requested
+        // and pinned together so that one scalar-memory round trip covers both
+        for (int w0 = 0; w0 < B; w0 += 32) {
+            uint32_t word = 0;
+            const int lim = min(32, B - w0);
+            for (int k = 0; k < lim; k += 2) {
+                obb_consts bx[2];
+                bx[0] = load_obb(boxes[w0 + k]);
+                bx[1] = load_obb(boxes[w0 + min(k + 1, lim - 1)]);
+                pin(bx[0]); pin(bx[1]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const double d0 = p.x - bx[u].c[0], d1 = p.y - bx[u].c[1], d2 = p.z - bx[u].c[2];
+                    bool in = live & (k + u < lim);
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
-                        const double pr = (d0 * bx.R[a] + d1 * bx.R[3 + a]) + d2 * bx.R[6 + a];
-                        in = in & (fabs(pr) <= bx.extent[a] / 2);
+                        const double pr = (d0 * bx[u].R[a] + d1 * bx[u].R[3 + a]) + d2 * bx[u].R[6 + a];
+                        in = in & (fabs(pr) <= bx[u].e[a] / 2);
                     }
-                    word |= in ? (1u << k) : 0u;
+                    word |= in ? (1u << ((k + u) & 31)) : 0u;
                 }
-                myb[((b0 + w0) >> 5) * F3D_BLOCK + tid] = word;
-                any |= word;
-                if (live && bits) bits[(size_t)i * words + ((b0 + w0) >> 5)] = word;
             }
+            myb[(w0 >> 5) * F3D_BLOCK + tid] = word;
+            any |= word;
+            if (live && bits) bits[(size_t)i * words + (w0 >> 5)] = word;
         }
         if (cooc && any) {
             for (int wa = 0; wa < words; ++wa) {
@@ -1128,7 +1141,7 @@ hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const
         hipError_t e = hipMemsetAsync(cooc, 0, (size_t)b * b, s);
         if (e != hipSuccess) return e;
     }
-    const size_t lds = (size_t)((b + 31) / 32) * F3D_BLOCK * sizeof(uint32_t) + F3D_OBB_CHUNK * sizeof(f3d_obb);
+    const size_t lds = (size_t)((b + 31) / 32) * F3D_BLOCK * sizeof(uint32_t);
     const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), blk(F3D_BLOCK);
     if (dtype == F3D_F64) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_in_obb<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
