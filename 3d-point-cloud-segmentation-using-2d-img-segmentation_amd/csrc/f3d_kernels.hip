@@ -979,7 +979,9 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 // launchers (called from f3d_capi.cpp)
 // =============================================================================================
 #define F3D_GRID_CAP (256 * 8 * 4)      // 256 CUs x 8 blocks, x4 so that tails stay short
+#ifndef F3D_FUSE_GRID
 #define F3D_FUSE_GRID (256 * 4 * 8)     // k_fuse: 4 resident blocks per CU (LDS limit), 8 rounds so that the tail stays short
+#endif
 
 hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], double* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
