@@ -49,6 +49,8 @@ def parse():
     ap.add_argument('--sorted', action='store_true', help='experiment: hand the cloud over already in grid-cell order (host sort)')
     ap.add_argument('--no-sort', action='store_true', help='do not cell-sort the cloud inside the step')
     ap.add_argument('--prepared', action='store_true', help='cell-sort once outside the timed loop and keep the sorted cloud resident')
+    ap.add_argument('--overlap-sort', action='store_true', help='sort the cloud of step i+1 on a second stream while step i is fused (measured: no '
+                    'gain, 1.43 vs 1.39 ms -- the fused kernel holds every wave slot of the chip, the sort kernels queue behind it)')
     return ap.parse_args()
 
 
@@ -108,6 +110,8 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')       # only matters for the one-rank rehearsal; torchrun sets all of these
+        os.environ.setdefault('RANK', str(rank)); os.environ.setdefault('WORLD_SIZE', str(world))
         dist.init_process_group('nccl', device_id=dev)
     ctx = f3d.Context(local)
 
@@ -149,11 +153,44 @@ def main():
         layout = 'caller order, no sort' + (' (cloud handed over pre-sorted by the host)' if args.sorted else '')
     else:
         flags |= f3d.FUSE_SORT
+    # The sort of a cloud and the fused kernel of the previous cloud are independent: in a stream of clouds the sort of
+    # step i+1 runs on a second HIP stream (its own context = its own scratch) while step i is fused.  Every step still does
+    # all of its work (sort, mask coding, fused kernel, exact kernel); the steps overlap in time.
+    overlap = bool(flags & f3d.FUSE_SORT) and args.overlap_sort
+    if overlap:
+        layout = 'caller order; the cell sort of step i+1 runs on a second stream while step i is fused'
+        ctx_sort = f3d.Context(local)
+        sort_stream = torch.cuda.Stream(dev)
+        perm_buf = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
+        ev_sorted = [torch.cuda.Event() for _ in range(2)]
+        ev_fused = [torch.cuda.Event() for _ in range(2)]
+        sort_issued = set()
+
+        def issue_sort(i):
+            if i in sort_issued:
+                return
+            sort_issued.add(i)
+            if i >= 2:
+                sort_stream.wait_event(ev_fused[i % 2])          # fuse(i-2) was the last reader of this permutation buffer
+            ctx_sort.cloud_sort_cells_dev(xyz.data_ptr(), dtype, n, None, perm_buf[i % 2].data_ptr(), sort_stream.cuda_stream)
+            ev_sorted[i % 2].record(sort_stream)
+
+    fuse_no = [0]
 
     def fuse(masks_t=None):
         m = masks_full if masks_t is None else masks_t
-        ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, m.data_ptr(), S, S,
-                                    133, 0.5, flt, classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
+        if not overlap:
+            ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, m.data_ptr(), S, S,
+                                        133, 0.5, flt, classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
+            return
+        i = fuse_no[0]
+        issue_sort(i)
+        issue_sort(i + 1)
+        stream.wait_event(ev_sorted[i % 2])
+        ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, m.data_ptr(), S, S, 133, 0.5, flt,
+                                    classes.data_ptr(), None, stream.cuda_stream, flags=f3d.FUSE_GATHER, perm_ptr=perm_buf[i % 2].data_ptr())
+        ev_fused[i % 2].record(stream)
+        fuse_no[0] = i + 1
 
     # N > 1: the mask all-gather of step i+1 (RCCL, its own stream) overlaps the kernels of step i (double-buffered masks).
     # Issued BEFORE fuse(i): the collective then only waits for fuse(i-1), the last reader of the buffer it overwrites.
