@@ -71,10 +71,46 @@ def test_load_csv(tmp_path):
     assert cid == [86, 114, 3] and pid == [1, 2, 5] and keep == [86, 114] and pname[0] == 'wall'
 
 
-def test_out_of_scope_entry_points_fail_loudly():
-    from Fusion3DSeg.process3D import process3DSeg
-    from Fusion3DSeg.fusion import Fusion
-    with pytest.raises(NotImplementedError):
-        process3DSeg('in', 'out')
-    with pytest.raises(NotImplementedError):
-        Fusion('tof', 'rts')
+def _write_capture(root, g, nframes):
+    """The on-disk layout Fusion(tof, rts) reads (reference fusion.py:17-47,67-77): a tof pickle listing per-frame pickles, an rts
+    pickle with the scaled intrinsics, depth resolution and (x,y,z,w) poses."""
+    import pickle
+    h, w = (int(x) for x in g['hw'])
+    merged = root / 'PointcloudMergeResults'
+    (merged / 'frames').mkdir(parents=True)
+    entries = []
+    for j in range(nframes):
+        rel = f'PointcloudMergeResults/frames/f{j}.pkl'
+        cam_z = np.full(h * w, 1.0); cam_z[~g['valid'][j]] = 0.0            # orgPoints only feed the range test on z
+        with open(root / rel, 'wb') as fp:
+            pickle.dump({'frameNumber': 100 + j, 'orgPoints': np.stack([cam_z * 0, cam_z * 0, cam_z], 1), 'modPoints': g['points'][j],
+                         'modSurfaceNormals': g['normals'][j], 'orgColorPoints': g['colors'][j]}, fp)
+        entries.append({'fileName': rel + ' \n'})
+    with open(merged / 'tofsegment_demo_1.pkl', 'wb') as fp:
+        pickle.dump(entries, fp)
+    with open(merged / 'rtscameradata_demo_1.pkl', 'wb') as fp:
+        pickle.dump({'Depth_res': (h, w), 'intrinsicScaled': g['K'], 'odo_wxyz': g['wxyz'][:, [1, 2, 3, 0]], 'odo_xyz': g['t']}, fp)
+    return merged
+
+
+def test_patch_downsample_and_frame_reader_match_reference_golden(golden, tmp_path):
+    """Host-side half of rows a5 / (f)#2 (no GPU): the first frame's lookup of the reference run is patch_downsample alone
+    (fusion.py:134-210, first draw of the seeded global generator), and FrameData reads the capture layout."""
+    from Fusion3DSeg.fusion import FrameData, Fusion, parse_rts
+    g = golden('fuse')
+    h, w = (int(x) for x in g['hw'])
+    np.random.seed(int(g['c0_params'][5]))
+    pcdimg = np.arange(h * w).reshape(h, w)
+    pt2u, pt2v = (np.arange(h * w) % w).astype(np.int32), (np.arange(h * w) // w).astype(np.int32)
+    pts, nrm, clr, uv2pt, nmerges = Fusion.patch_downsample(g['points'][0], g['normals'][0], g['colors'][0], h, w, 10, 0.05,
+                                                            np.cos(np.deg2rad(10)), pcdimg, pt2u, pt2v, g['valid'][0].copy().reshape(h, w))
+    assert uv2pt.dtype == np.int32 and np.array_equal(uv2pt, g['c0_uv2pt'][0])
+    assert len(pts) == len(nrm) == len(clr) == len(nmerges) == uv2pt.max() + 1 and nmerges.sum() == (uv2pt >= 0).sum()
+    merged = _write_capture(tmp_path, g, 2)
+    K, rw, rh, wxyz, t = parse_rts(merged / 'rtscameradata_demo_1.pkl')
+    assert (rw, rh) == (w, h) and np.array_equal(wxyz, g['wxyz']) and np.array_equal(K, g['K'])
+    fd = FrameData(str(merged / 'tofsegment_demo_1.pkl'), point_range=(0.1, 4), decimation=1, depth_hw=(h, w))
+    name, p1, n1, c1, ok = fd[1]
+    assert len(fd) == 2 and name == '101' and np.array_equal(p1, g['points'][1]) and np.array_equal(ok, g['valid'][1])
+    ok2 = FrameData(str(merged / 'tofsegment_demo_1.pkl'), None, 2, (h, w))[0][4]
+    assert ok2.reshape(h, w)[::2, ::2].all() and ok2.sum() == (h // 2) * (w // 2)

@@ -362,6 +362,59 @@ def test_unproject_depth_matches_reference_golden(golden):
         assert np.abs(have - want).max() <= 8 * np.finfo(float).eps * scale
 
 
+def test_fusion_fuse_matches_reference_golden(golden, tmp_path):
+    """Rows a5 / (f)#2: Fusion.fuse + patch_downsample against the reference's own run on a synthetic sequence
+    (tests/golden/make_golden_fuse.py): same shuffles from the seeded global generator, frustum cull + projection on the GPU."""
+    from Fusion3DSeg.fusion import Fusion
+    g = golden('fuse')
+    h, w = (int(x) for x in g['hw'])
+    F = len(g['points'])
+    for ci in range(int(g['ncases'])):
+        radius, angle, stride, max_depth, skip, seed = g[f'c{ci}_params']
+        frames = [(f'{100 + j}', g['points'][j].copy(), g['normals'][j].copy(), g['colors'][j].copy(), g['valid'][j].copy())
+                  for j in range(F)]
+        lookups = {}
+        fu = Fusion.from_frames(g['K'], w, h, g['wxyz'], g['t'], frames, lookup_dir=tmp_path if ci == 0 else None,
+                                lookup_sink=lambda name, lut: lookups.__setitem__(name, np.array(lut, copy=True)))
+        np.random.seed(int(seed))
+        pts, nrm, clr, nmerges, occ = fu.fuse(float(radius), float(angle), None if stride < 0 else int(stride), float(max_depth), int(skip))
+        assert np.array_equal(nmerges, g[f'c{ci}_nmerges']) and np.array_equal(occ, g[f'c{ci}_occurences']), ci
+        assert occ.dtype == np.uint32
+        assert sorted(int(k) for k in lookups) == g[f'c{ci}_uv2pt_names'].tolist()
+        for name, want in zip(g[f'c{ci}_uv2pt_names'], g[f'c{ci}_uv2pt']):
+            assert lookups[str(name)].dtype == np.int32 and np.array_equal(lookups[str(name)], want), (ci, name)
+        for got, key in ((pts, 'ds_pts'), (nrm, 'ds_norms'), (clr, 'ds_clrs')):
+            assert np.array_equal(got, g[f'c{ci}_{key}']), (ci, key)
+        if ci == 0:                                                        # the .npy lookups the voting stage reads
+            assert np.array_equal(np.load(tmp_path / '100.npy'), g['c0_uv2pt'][0])
+            fu.dump_data(tmp_path / 'out', pts, nrm, clr, nmerges, occ)
+            back = Fusion.load_data(tmp_path / 'out')
+            assert np.array_equal(back[0], pts) and back[5] == F and tuple(back[6]) == (h, w)
+            from sklearn.neighbors import KDTree
+            ref_adj = KDTree(pts).query_radius(pts, r=2 * float(radius))
+            assert all(np.array_equal(np.sort(a), np.sort(b)) for a, b in zip(back[7], ref_adj))
+            assert (tmp_path / 'out' / 'fusion' / 'fusion_0_05_10.0.ply').is_file()
+
+
+def test_process3dseg_end_to_end_from_capture_files(golden, tmp_path):
+    """process3D.py:14-68 on a capture written to disk: same cloud as the in-memory run, fusion directory complete."""
+    from test_mirror_cpu import _write_capture
+    from Fusion3DSeg.fusion import Fusion
+    from Fusion3DSeg.process3D import process3DSeg
+    g = golden('fuse')
+    F = len(g['points'])
+    _write_capture(tmp_path / 'capture', g, F)
+    np.random.seed(11)
+    pts, nrm, clr, nmerges, occ, nframes, hw, adj = process3DSeg(str(tmp_path / 'capture'), str(tmp_path / 'out'), radius=0.05, angle=10,
+                                                                 stride=10, point_range=(0.1, 10), decimation=1, min_occ=3)
+    assert np.array_equal(pts, g['c0_ds_pts']) and np.array_equal(nmerges, g['c0_nmerges']) and np.array_equal(occ, g['c0_occurences'])
+    assert nframes == F and len(adj) == len(pts)
+    lut_dir = tmp_path / 'capture' / 'fusion' / 'uv2pt'
+    assert sorted(p.name for p in lut_dir.glob('*.npy')) == [f'{100 + j}.npy' for j in range(F)]
+    assert np.array_equal(np.load(lut_dir / '102.npy'), g['c0_uv2pt'][2])
+    assert (tmp_path / 'out' / 'fusion' / 'fusion_data.pkl').is_file() and (tmp_path / 'out' / 'fusion' / 'adj.pkl').is_file()
+
+
 def test_other_intersections_primitives_match_reference_golden(golden):
     import Fusion3DSeg.intersections as I
     g = golden('intersections')
