@@ -209,29 +209,33 @@ class Fusion:
                 x_mrg, x_occ = nmerges[hits], occurences[hits]
                 uv = uv_all[:, hits]
                 free = q_valid.reshape(self.h, self.w)                      # a view: the frame's mask is consumed, as in the reference
-                left = self.npts
-                for k in range(len(ids)):
-                    if not left:
-                        break
-                    cu, cv = uv[0, k], uv[1, k]
-                    win = np.s_[max(0, cv - half):cv + half + 1, max(0, cu - half):cu + half + 1]
-                    open_px = free[win].reshape(-1)
-                    if not open_px.any():
-                        continue
-                    cand = self.pcdimg[win].reshape(-1)[open_px]
-                    take = _mergeable(x_pts[k], x_nrm[k], q_pts[cand], q_nrm[cand], radius, min_cosine)
-                    n_take = take.sum()
-                    if not n_take:
-                        continue
-                    left -= n_take
-                    members = cand[take]
-                    x_pts[k] = np.mean(np.vstack([q_pts[members], x_pts[k][None, :]]), axis=0)
-                    x_clr[k] = np.mean(np.vstack([q_clr[members], x_clr[k][None, :]]), axis=0)
-                    nsum = np.mean(np.vstack([q_nrm[members], x_nrm[k][None, :]]), axis=0)
-                    x_nrm[k] = nsum / np.linalg.norm(nsum)
-                    x_mrg[k] += n_take
-                    x_occ[k] += 1
-                    uv2pt[members] = ids[k]
+                # The reference visits the seeds in index order and lets each take the free pixels of its window that pass the
+                # criterion (:269-298).  A seed's criterion uses its own position / normal from BEFORE this frame, so the result
+                # is: a free pixel belongs to the first seed whose window covers it and accepts it -- one HIP launch.
+                owner = ctx.patch_owner(uv, x_pts, x_nrm, q_pts, q_nrm, free.reshape(-1), self.h, self.w, half, radius, min_cosine)
+                taken = np.nonzero(owner >= 0)[0]                           # ascending pixel id = row-major order inside every window
+                if len(taken):
+                    by_seed = np.argsort(owner[taken], kind='stable')
+                    members, seed_of = taken[by_seed], owner[taken][by_seed]
+                    seeds, first, n_take = np.unique(seed_of, return_index=True, return_counts=True)
+
+                    def sum_in_order(rows):                                 # per seed: ((r0 + r1) + r2) + ..., as np.mean adds rows
+                        acc = rows[first].copy()
+                        for r in range(1, int(n_take.max())):
+                            more = n_take > r
+                            acc[more] += rows[first[more] + r]
+                        return acc
+
+                    denom = (n_take + 1)[:, None]                           # the seed itself is the last row of the reference's vstack
+                    x_pts[seeds] = (sum_in_order(q_pts[members]) + x_pts[seeds]) / denom
+                    x_clr[seeds] = (sum_in_order(q_clr[members]) + x_clr[seeds]) / denom
+                    nsum = (sum_in_order(q_nrm[members]) + x_nrm[seeds]) / denom
+                    # np.linalg.norm of ONE vector goes through BLAS ddot (FMA, kernel dependent), unlike the axis=-1 form:
+                    # taken per vector so that the bits are the reference's
+                    x_nrm[seeds] = nsum / np.array([np.linalg.norm(v) for v in nsum])[:, None]
+                    x_mrg[seeds] += n_take
+                    x_occ[seeds] += 1
+                    uv2pt[members] = ids[seed_of]
                     free[self.pt2v[members], self.pt2u[members]] = False
                 pts[hits], nrm[hits], clr[hits] = x_pts, x_nrm, x_clr
                 nmerges[hits], occurences[hits] = x_mrg, x_occ

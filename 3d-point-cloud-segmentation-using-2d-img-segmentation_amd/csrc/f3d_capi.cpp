@@ -20,7 +20,7 @@ static_assert(sizeof(f3d_view) == 640, "f3d_view is 80 doubles");
 namespace {
 
 enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_SORT_PERM, SLOT_SORT_SCRATCH,
-       SLOT_TILED_MASKS, SLOT_TODO, SLOT_GRAPH, SLOT_GRAPH_BBOX, SLOT_COUNT };
+       SLOT_TILED_MASKS, SLOT_TODO, SLOT_GRAPH, SLOT_GRAPH_BBOX, SLOT_PATCH, SLOT_COUNT };
 
 thread_local char g_create_err[512] = "";
 
@@ -864,6 +864,55 @@ int f3d_components_same_class(f3d_ctx* ctx, const int64_t* classes, int64_t n, c
                                             (int64_t*)droot, s))) return rc;
     if ((rc = take_error(ctx, s))) return rc;
     F3D_HIP(ctx, hipMemcpyAsync(root, droot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5 patch matching of Fusion.fuse
+// ---------------------------------------------------------------------------------------------
+int f3d_patch_owner_dev(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w, int half, double radius, double min_cosine,
+                        const double* seed_pts, const double* seed_nrm, const double* q_pts, const double* q_nrm,
+                        const uint8_t* free_px, int32_t* owner, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t npx = (int64_t)h * w;
+    if (h < 0 || w < 0 || m < 0 || half < 0 || npx > 0x7fffffffLL || m > 0x7fffffffLL || (m > 0 && (!uv || !seed_pts || !seed_nrm)) ||
+        (npx > 0 && (!q_pts || !q_nrm || !free_px || !owner)))
+        return fail(ctx, F3D_ERR_INVALID, "patch_owner: bad arguments");
+    if (npx == 0) return F3D_OK;
+    void* scratch;
+    if ((rc = ensure(ctx, SLOT_PATCH, f3d_patch_scratch_bytes(h, w, m), &scratch))) return rc;
+    F3D_HIP(ctx, f3d_launch_patch_owner(uv, m, h, w, half, radius, min_cosine, seed_pts, seed_nrm, q_pts, q_nrm, free_px, owner, scratch,
+                                        pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_patch_owner(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w, int half, double radius, double min_cosine,
+                    const double* seed_pts, const double* seed_nrm, const double* q_pts, const double* q_nrm,
+                    const uint8_t* free_px, int32_t* owner) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t npx = (int64_t)h * w;
+    if (h < 0 || w < 0 || m < 0 || (m > 0 && (!uv || !seed_pts || !seed_nrm)) || (npx > 0 && (!q_pts || !q_nrm || !free_px || !owner)))
+        return fail(ctx, F3D_ERR_INVALID, "patch_owner: bad arguments");
+    if (npx == 0) return F3D_OK;
+    void *duv, *dsp, *dsn, *dqp, *dqn, *dfree, *down;
+    if ((rc = ensure(ctx, SLOT_AUX0, (size_t)m * 8 + 8, &duv)) || (rc = ensure(ctx, SLOT_XYZ, (size_t)m * 24 + 8, &dsp)) ||
+        (rc = ensure(ctx, SLOT_OUT1, (size_t)m * 24 + 8, &dsn)) || (rc = ensure(ctx, SLOT_MASKS, (size_t)npx * 24, &dqp)) ||
+        (rc = ensure(ctx, SLOT_VIEWS, (size_t)npx * 24, &dqn)) || (rc = ensure(ctx, SLOT_AUX1, (size_t)npx, &dfree)) ||
+        (rc = ensure(ctx, SLOT_OUT0, (size_t)npx * 4, &down)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    if (m) {
+        F3D_HIP(ctx, hipMemcpyAsync(duv, uv, (size_t)m * 8, hipMemcpyHostToDevice, s));
+        F3D_HIP(ctx, hipMemcpyAsync(dsp, seed_pts, (size_t)m * 24, hipMemcpyHostToDevice, s));
+        F3D_HIP(ctx, hipMemcpyAsync(dsn, seed_nrm, (size_t)m * 24, hipMemcpyHostToDevice, s));
+    }
+    F3D_HIP(ctx, hipMemcpyAsync(dqp, q_pts, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dqn, q_nrm, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dfree, free_px, (size_t)npx, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_patch_owner_dev(ctx, (const int32_t*)duv, m, h, w, half, radius, min_cosine, (const double*)dsp, (const double*)dsn,
+                                  (const double*)dqp, (const double*)dqn, (const uint8_t*)dfree, (int32_t*)down, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(owner, down, (size_t)npx * 4, hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
     return F3D_OK;
 }

@@ -80,6 +80,11 @@ hipError_t f3d_launch_graph_count(const void* xyz, int dtype, int64_t n, const f
                                   int64_t* offsets, hipStream_t s);
 hipError_t f3d_launch_graph_fill(int64_t n, const f3d_graphgrid& g, double r2, const void* scratch, const int64_t* offsets,
                                  int32_t* nbrs, hipStream_t s);
+// a5 patch matching (f3d_patch.hip): owner[p] = first seed (lowest index) whose window covers free pixel p and accepts it, -1 if none
+size_t f3d_patch_scratch_bytes(int h, int w, int64_t m);
+hipError_t f3d_launch_patch_owner(const int32_t* uv, int64_t m, int h, int w, int half, double radius, double min_cosine,
+                                  const double* seed_pts, const double* seed_nrm, const double* q_pts, const double* q_nrm,
+                                  const uint8_t* free_px, int32_t* owner, void* scratch, hipStream_t s);
 // a12: remaining intersections.py primitives (f3d_geom.hip), device pointers
 hipError_t f3d_launch_ray_x_lines(const double o[3], const double d[3], const double* starts, const double* ends, int64_t n, double* pts,
                                   uint8_t* within, hipStream_t s);

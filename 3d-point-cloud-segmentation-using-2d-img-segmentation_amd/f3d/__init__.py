@@ -100,6 +100,8 @@ def library():
         'f3d_lines_plane_projection': (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         'f3d_components_same_class': (i32, [vp, vp, i64, vp, vp, vp]),
         'f3d_components_same_class_dev': (i32, [vp, vp, i64, vp, vp, vp, vp, vp]),
+        'f3d_patch_owner': (i32, [vp, vp, i64, i32, i32, i32, dbl, dbl, vp, vp, vp, vp, vp, vp]),
+        'f3d_patch_owner_dev': (i32, [vp, vp, i64, i32, i32, i32, dbl, dbl, vp, vp, vp, vp, vp, vp, vp]),
         'f3d_unproject_depth': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp]),
         'f3d_unproject_depth_dev': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp, vp]),
         'f3d_radius_graph_count': (i32, [vp, vp, i32, i64, dbl, vp, vp]),
@@ -399,6 +401,21 @@ class Context:
         root = np.empty(len(cls), np.int64)
         self._check(self._lib.f3d_components_same_class(self._h, _ptr(cls), len(cls), _ptr(offs), _ptr(nb), _ptr(root)))
         return root
+
+    def patch_owner(self, uv, seed_pts, seed_normals, frame_pts, frame_normals, free, h, w, half, radius, min_cosine):
+        """owner int32 [h*w]: for every free depth pixel the first seed of Fusion.fuse's matching loop (fusion.py:269-298)
+        that would take it, -1 if none."""
+        uv = np.ascontiguousarray(uv, dtype=np.int32)
+        sp, sn = _f64(seed_pts), _f64(seed_normals)
+        qp, qn = _f64(frame_pts, (h * w, 3)), _f64(frame_normals, (h * w, 3))
+        fr = np.ascontiguousarray(free, dtype=np.uint8).reshape(-1)
+        m = len(sp)
+        if uv.shape != (2, m) or sn.shape != (m, 3) or len(fr) != h * w:
+            raise ValueError('patch_owner: uv must be [2,m], seeds [m,3], free [h*w]')
+        owner = np.empty(h * w, np.int32)
+        self._check(self._lib.f3d_patch_owner(self._h, _ptr(uv), m, h, w, int(half), float(radius), float(min_cosine), _ptr(sp), _ptr(sn),
+                                              _ptr(qp), _ptr(qn), _ptr(fr), _ptr(owner)))
+        return owner
 
     def unproject_depth(self, depth, K, q_wxyz, t, depth_scale=1000.0):
         """Depth frame [H,W] (uint16, float32 or float64) -> world points float64 [H*W,3] (ios_rtab.py:171-173,187-192)."""

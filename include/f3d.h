@@ -280,6 +280,21 @@ int f3d_radius_graph_count_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, i
 int f3d_radius_graph_fill_dev(f3d_ctx* ctx, int64_t n, const int64_t* offsets /*device*/,
                               int32_t* neighbours /*device [nnz]*/, void* stream);
 
+/* ---- a5: patch matching of Fusion.fuse (Fusion3DSeg/fusion.py:269-298) ------------------- */
+/* The loop over the in-frustum points ("seeds", in index order) of one frame: seed k takes the still-free depth pixels of
+ * the (2*half+1)^2 window around its projection uv[:,k] that lie within `radius` of it and whose normals satisfy
+ * dot > min_cosine, judged with the seed's position / normal from before the frame.  Equivalent, and what is computed:
+ * owner[p] = the lowest k whose window covers free pixel p and whose test accepts it, -1 if none (or not free).
+ * uv int32 [2,m] (row 0 = u, row 1 = v, as points2pixel returns it), seeds [m,3], frame points / normals [h*w,3],
+ * free uint8 [h*w] (non_merged), owner int32 [h*w].  The test reproduces NumPy's evaluation order (norm(axis=-1),
+ * einsum 'ij,j->i') and the window the reference's slice arithmetic, negative stops included. */
+int f3d_patch_owner(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w, int half, double radius, double min_cosine,
+                    const double* seed_pts, const double* seed_normals, const double* frame_pts,
+                    const double* frame_normals, const uint8_t* free_px, int32_t* owner);
+int f3d_patch_owner_dev(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w, int half, double radius,
+                        double min_cosine, const double* seed_pts, const double* seed_normals, const double* frame_pts,
+                        const double* frame_normals, const uint8_t* free_px, int32_t* owner, void* stream);
+
 /* ---- (f)#3: depth frame -> world points (RTAB_utils/ios_rtab.py) -------------------------- */
 /* RTAB2Cache.__getRGBP3d (:171-173): x = (px - cx) * (d / fx), y = (py - cy) * (d / fy), z = d with the scaled
  * intrinsics K and the integer pixel grid; __getModP3d: divided by depth_scale (1000: mm -> m, :187), rotated by the

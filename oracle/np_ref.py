@@ -417,6 +417,42 @@ def unproject_depth(depth, K, q_wxyz, t, depth_scale=1000):
     return rotate(q_wxyz, pts) + np.asarray(t, np.float64)                                # :190-192
 
 
+def fuse_match_frame(uv, x_pts, x_nrm, x_clr, x_mrg, x_occ, ids, q_pts, q_nrm, q_clr, free, h, w, half, radius, min_cosine):
+    """The per-frame matching loop of Fusion.fuse (fusion.py:269-298), literally: seeds in index order, each taking the free pixels
+    of its window that pass the criterion (:223-228), arrays updated in place.  Returns the frame's uv2pt (int32 [h*w], -1 = none).
+    Pinned through tests/golden/fuse.npz (the reference's own run); used to check the data-parallel formulation on random frames."""
+    pcdimg = np.arange(h * w).reshape(h, w)
+    pt2u, pt2v = np.arange(h * w) % w, np.arange(h * w) // w
+    uv2pt = np.full(h * w, -1, np.int32)
+    count = h * w
+    for i_, (idx, (u_, v_)) in enumerate(zip(ids, np.asarray(uv).T)):
+        if not count:
+            break
+        starti, endi = max(0, v_ - half), v_ + half + 1
+        startj, endj = max(0, u_ - half), u_ + half + 1
+        patch = pcdimg[starti:endi, startj:endj].reshape(-1)
+        valid = free[starti:endi, startj:endj].reshape(-1)
+        if not valid.any():
+            continue
+        patch = patch[valid]
+        p_pts, p_nrm, p_clr = q_pts[patch], q_nrm[patch], q_clr[patch]
+        dist = np.linalg.norm(p_pts - x_pts[i_][None, :], axis=-1)
+        mask = (dist < radius) & (np.einsum('ij, j -> i', p_nrm, x_nrm[i_]) > min_cosine)
+        matches = mask.sum()
+        if matches:
+            count -= matches
+            x_pts[i_] = np.mean(np.vstack([p_pts[mask], x_pts[i_][None, :]]), axis=0)
+            x_clr[i_] = np.mean(np.vstack([p_clr[mask], x_clr[i_][None, :]]), axis=0)
+            n = np.mean(np.vstack([p_nrm[mask], x_nrm[i_][None, :]]), axis=0)
+            x_nrm[i_] = n / np.linalg.norm(n)
+            x_mrg[i_] += matches
+            x_occ[i_] += 1
+            merged = patch[mask]
+            uv2pt[merged] = idx
+            free[pt2v[merged], pt2u[merged]] = False
+    return uv2pt
+
+
 def radius_adjacency(points, r):
     """fusion.py:374-375: KDTree(points).query_radius(points, r) -- brute force over all pairs with the tree's leaf test:
     sklearn's euclidean_rdist accumulates (x1[j] - x2[j])**2 for j = 0, 1, 2 in that order and query_radius keeps

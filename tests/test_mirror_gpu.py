@@ -396,6 +396,31 @@ def test_fusion_fuse_matches_reference_golden(golden, tmp_path):
             assert (tmp_path / 'out' / 'fusion' / 'fusion_0_05_10.0.ply').is_file()
 
 
+def test_patch_owner_kernel_matches_the_sequential_matching_loop():
+    """a5: the data-parallel ownership formulation against the literal loop (oracle, pinned by fuse.npz) on random frames,
+    seeds projecting outside the image (Python slice semantics of the window) included."""
+    ctx = f3d.default_context()
+    rng = np.random.default_rng(41)
+    for trial, (h, w, half, m) in enumerate([(20, 28, 3, 900), (33, 17, 5, 400), (8, 8, 9, 60), (16, 16, 0, 300)]):
+        q_pts = rng.uniform(0, 1, (h * w, 3)) * [1, 1, 0.05]
+        q_nrm = rng.normal(size=(h * w, 3)); q_nrm /= np.linalg.norm(q_nrm, axis=1, keepdims=True)
+        q_nrm[:, 2] = np.abs(q_nrm[:, 2]) + 1.0; q_nrm /= np.linalg.norm(q_nrm, axis=1, keepdims=True)
+        free = rng.random((h, w)) < 0.85
+        pix = rng.integers(0, h * w, m)
+        x_pts = q_pts[pix] + rng.normal(0, 0.02, (m, 3))
+        x_nrm = q_nrm[pix].copy()
+        uv = np.stack([pix % w, pix // w]).astype(np.int32)
+        uv[:, :12] += rng.integers(-2 * max(h, w), 2 * max(h, w), (2, 12)).astype(np.int32)     # seeds off the image, both signs
+        radius, min_cos = 0.12, np.cos(np.deg2rad(35))
+        owner = ctx.patch_owner(uv, x_pts, x_nrm, q_pts, q_nrm, free.reshape(-1), h, w, half, radius, min_cos)
+        want = O.fuse_match_frame(uv, x_pts.copy(), x_nrm.copy(), np.zeros((m, 3)), np.zeros(m, np.int64), np.zeros(m, np.uint32),
+                                  np.arange(m), q_pts, q_nrm, np.zeros((h * w, 3)), free.copy(), h, w, half, radius, min_cos)
+        assert owner.dtype == np.int32 and np.array_equal(owner, want), trial
+        assert (owner >= 0).sum() > 20
+    assert np.array_equal(ctx.patch_owner(np.zeros((2, 0), np.int32), np.zeros((0, 3)), np.zeros((0, 3)), q_pts, q_nrm,
+                                          free.reshape(-1), h, w, half, 0.1, 0.5), np.full(h * w, -1, np.int32))
+
+
 def test_process3dseg_end_to_end_from_capture_files(golden, tmp_path):
     """process3D.py:14-68 on a capture written to disk: same cloud as the in-memory run, fusion directory complete."""
     from test_mirror_cpu import _write_capture
