@@ -146,12 +146,54 @@ class Fusion:
                          pcdimg, pt2u, pt2v, non_merged=None):
         """One frame -> representative points (reference :134-210): visit the pixels in a random order; a pixel that is still
         free becomes a seed, absorbs the free pixels of its (stride x stride) window that satisfy the merge criterion and
-        is replaced by their mean.  Returns (points, normals, colours, uv2pt int32 [h*w] with -1 = none, merge counts)."""
+        is replaced by their mean.  Returns (points, normals, colours, uv2pt int32 [h*w] with -1 = none, merge counts).
+
+        "Still free when visited" is the only sequential coupling, and it is local: pixel p is a seed iff no EARLIER seed whose
+        window covers it accepts it.  The HIP kernels settle that in a few data-parallel rounds and return, per pixel, the seed
+        that takes it; the host then only adds the members of every seed in the reference's order."""
         order = np.arange(len(points))
         np.random.shuffle(order)                                              # the global generator, as the reference (:172)
         free = np.ones((height, width), dtype=bool) if non_merged is None else non_merged   # updated in place, like the reference
+        half = stride // 2
+        points, normals = np.asarray(points, np.float64), np.asarray(normals, np.float64)
+        flat_free = free.reshape(-1)
+        own_cos = np.einsum('ij,ij->i', normals, normals)
+        usable = (own_cos > min_cosine) & np.isfinite(points).all(axis=1)
+        if len(points) != height * width or not (max_distance > 0) or (flat_free & ~usable).any():
+            # a free pixel that would not accept itself (zero / NaN normal): the reference then averages an empty set and leaves the
+            # pixel to later seeds -- keep its literal order of events for such frames
+            return cls._patch_downsample_sequential(order, points, normals, colors, height, width, half, max_distance, min_cosine,
+                                                    pcdimg, pt2u, pt2v, free)
+        prio = np.empty(len(points), np.int32)
+        prio[order] = np.arange(len(points), dtype=np.int32)
+        owner, _ = f3d.default_context().patch_seeds(points, normals, prio, flat_free, height, width, half, max_distance, min_cosine)
         uv2pt = np.full(height * width, -1, np.int32)
-        left, half = height * width, stride // 2
+        taken = np.nonzero(owner >= 0)[0]                                    # ascending pixel id = row-major order inside every window
+        if not len(taken):
+            return np.array([]), np.array([]), np.array([]), uv2pt, np.array([])
+        by_seed = np.argsort(prio[owner[taken]], kind='stable')              # seeds in visiting order, members ascending inside
+        members = taken[by_seed]
+        _, first, n_take = np.unique(prio[owner[members]], return_index=True, return_counts=True)
+
+        def mean_in_order(rows):                                             # per seed ((r0 + r1) + r2) + ... then / n, as np.mean does
+            acc = rows[first].copy()
+            for r in range(1, int(n_take.max())):
+                more = n_take > r
+                acc[more] += rows[first[more] + r]
+            return acc / n_take[:, None]
+
+        colors = np.asarray(colors)
+        out_p, out_c, nsum = mean_in_order(points[members]), mean_in_order(colors[members]), mean_in_order(normals[members])
+        out_n = nsum / np.array([np.linalg.norm(v) for v in nsum])[:, None]  # one ddot per vector: the reference's bits
+        uv2pt[members] = np.repeat(np.arange(len(first), dtype=np.int32), n_take)
+        free[pt2v[members], pt2u[members]] = False
+        return out_p, out_n, out_c, uv2pt, n_take
+
+    @staticmethod
+    def _patch_downsample_sequential(order, points, normals, colors, height, width, half, max_distance, min_cosine, pcdimg, pt2u, pt2v, free):
+        """The literal order of events of reference :176-208 (used only for frames the data-parallel form does not cover)."""
+        uv2pt = np.full(height * width, -1, np.int32)
+        left = height * width
         out_p, out_n, out_c, out_m = [], [], [], []
         for seed in order:
             su, sv = pt2u[seed], pt2v[seed]

@@ -917,6 +917,34 @@ int f3d_patch_owner(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w, in
     return F3D_OK;
 }
 
+int f3d_patch_seeds(f3d_ctx* ctx, const double* pts, const double* nrm, const int32_t* prio, const uint8_t* free_px, int h, int w,
+                    int half, double radius, double min_cosine, int32_t* owner, int32_t* rounds) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t npx = (int64_t)h * w;
+    if (h < 0 || w < 0 || half < 0 || npx > 0x7fffffffLL || (npx > 0 && (!pts || !nrm || !prio || !free_px || !owner)))
+        return fail(ctx, F3D_ERR_INVALID, "patch_seeds: bad arguments");
+    if (rounds) *rounds = 0;
+    if (npx == 0) return F3D_OK;
+    void *dp, *dn, *dprio, *dfree, *dstat, *down;
+    if ((rc = ensure(ctx, SLOT_MASKS, (size_t)npx * 24, &dp)) || (rc = ensure(ctx, SLOT_VIEWS, (size_t)npx * 24, &dn)) ||
+        (rc = ensure(ctx, SLOT_AUX0, (size_t)npx * 4, &dprio)) || (rc = ensure(ctx, SLOT_AUX1, (size_t)npx, &dfree)) ||
+        (rc = ensure(ctx, SLOT_PATCH, (size_t)npx * 4 + 256, &dstat)) || (rc = ensure(ctx, SLOT_OUT0, (size_t)npx * 4, &down)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dp, pts, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dn, nrm, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dprio, prio, (size_t)npx * 4, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dfree, free_px, (size_t)npx, hipMemcpyHostToDevice, s));
+    int r = 0;
+    int32_t* counter = (int32_t*)((char*)dstat + (((size_t)npx * 4 + 63) & ~(size_t)63));
+    F3D_HIP(ctx, f3d_launch_patch_seeds((const double*)dp, (const double*)dn, (const int32_t*)dprio, (const uint8_t*)dfree, h, w, half, radius,
+                                        min_cosine, (int32_t*)dstat, (int32_t*)down, counter, &r, s));
+    F3D_HIP(ctx, hipMemcpyAsync(owner, down, (size_t)npx * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    if (rounds) *rounds = r;
+    return F3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // (f)#1 adjacency: KDTree(points).query_radius(points, r) (fusion.py:374-375) as CSR
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,9 @@ size_t f3d_patch_scratch_bytes(int h, int w, int64_t m);
 hipError_t f3d_launch_patch_owner(const int32_t* uv, int64_t m, int h, int w, int half, double radius, double min_cosine,
                                   const double* seed_pts, const double* seed_nrm, const double* q_pts, const double* q_nrm,
                                   const uint8_t* free_px, int32_t* owner, void* scratch, hipStream_t s);
+hipError_t f3d_launch_patch_seeds(const double* pts, const double* nrm, const int32_t* prio, const uint8_t* free_px, int h, int w, int half,
+                                  double radius, double min_cosine, int32_t* status, int32_t* owner, int32_t* counter, int* rounds,
+                                  hipStream_t s);
 // a12: remaining intersections.py primitives (f3d_geom.hip), device pointers
 hipError_t f3d_launch_ray_x_lines(const double o[3], const double d[3], const double* starts, const double* ends, int64_t n, double* pts,
                                   uint8_t* within, hipStream_t s);

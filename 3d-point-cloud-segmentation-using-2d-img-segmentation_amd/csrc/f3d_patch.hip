@@ -102,6 +102,68 @@ __global__ __launch_bounds__(PB) void k_patch_owner(const int32_t* __restrict__ 
     }
 }
 
+// ---- patch_downsample (fusion.py:134-210): which pixels become seeds.  Pixel p (visited at position prio[p] of the shuffled
+// order) is a seed iff it is still free then, i.e. iff no EARLIER seed whose window covers it accepts it.  Resolved in rounds:
+// an undecided pixel becomes "claimed" as soon as one earlier accepting neighbour is known to be a seed, and "seed" once all
+// of them are known not to be; the earliest undecided pixel always resolves, typical depth is a handful of rounds.
+enum { PD_UNKNOWN = 0, PD_SEED = 1, PD_CLAIMED = 2, PD_NOT_FREE = 3 };
+
+__device__ __forceinline__ bool accepts_px(const double* __restrict__ pts, const double* __restrict__ nrm, int64_t seed, int64_t cand,
+                                           const patch_args& a) {
+    // criterion(ds = seed, points = candidates): candidate minus seed, candidate normal . seed normal
+    return accepts(pts, nrm, seed, pts[3 * cand], pts[3 * cand + 1], pts[3 * cand + 2], nrm[3 * cand], nrm[3 * cand + 1], nrm[3 * cand + 2], a);
+}
+
+__global__ __launch_bounds__(PB) void k_pd_init(const uint8_t* __restrict__ free_px, int64_t npx, int32_t* __restrict__ status) {
+    for (int64_t p = (int64_t)blockIdx.x * PB + threadIdx.x; p < npx; p += (int64_t)gridDim.x * PB) status[p] = free_px[p] ? PD_UNKNOWN : PD_NOT_FREE;
+}
+
+__global__ __launch_bounds__(PB) void k_pd_round(const double* __restrict__ pts, const double* __restrict__ nrm, const int32_t* __restrict__ prio,
+                                                  patch_args a, int32_t* status, int32_t* __restrict__ unknown_left) {
+    const int64_t npx = (int64_t)a.h * a.w;
+    for (int64_t p = (int64_t)blockIdx.x * PB + threadIdx.x; p < npx; p += (int64_t)gridDim.x * PB) {
+        if (__atomic_load_n(&status[p], __ATOMIC_RELAXED) != PD_UNKNOWN) continue;
+        const int v = (int)(p / a.w), u = (int)(p - (int64_t)v * a.w), mine = prio[p];
+        const int v0 = max(0, v - a.half), v1 = min(a.h - 1, v + a.half), u0 = max(0, u - a.half), u1 = min(a.w - 1, u + a.half);
+        bool claimed = false, waiting = false;
+        for (int sv = v0; sv <= v1 && !claimed; ++sv)
+            for (int su = u0; su <= u1; ++su) {
+                const int64_t q = (int64_t)sv * a.w + su;
+                if (prio[q] >= mine) continue;                                   // only earlier pixels can have taken p
+                const int st = __atomic_load_n(&status[q], __ATOMIC_RELAXED);
+                if (st == PD_CLAIMED || st == PD_NOT_FREE) continue;             // never a seed
+                if (!accepts_px(pts, nrm, q, p, a)) continue;
+                if (st == PD_SEED) { claimed = true; break; }
+                waiting = true;                                                  // q undecided: it may still turn out to be a seed
+            }
+        if (claimed) __atomic_store_n(&status[p], PD_CLAIMED, __ATOMIC_RELAXED);
+        else if (!waiting) __atomic_store_n(&status[p], PD_SEED, __ATOMIC_RELAXED);
+        else atomicAdd(unknown_left, 1);
+    }
+}
+
+// owner[p]: the seed (pixel index) that takes pixel p = the earliest seed that covers and accepts it; a seed takes itself when it
+// accepts itself; -1 for pixels nobody takes
+__global__ __launch_bounds__(PB) void k_pd_owner(const double* __restrict__ pts, const double* __restrict__ nrm, const int32_t* __restrict__ prio,
+                                                  patch_args a, const int32_t* __restrict__ status, int32_t* __restrict__ owner) {
+    const int64_t npx = (int64_t)a.h * a.w;
+    for (int64_t p = (int64_t)blockIdx.x * PB + threadIdx.x; p < npx; p += (int64_t)gridDim.x * PB) {
+        int best = -1, best_prio = 0x7fffffff;
+        const int st = status[p];
+        if (st == PD_SEED || st == PD_CLAIMED) {
+            const int v = (int)(p / a.w), u = (int)(p - (int64_t)v * a.w);
+            const int v0 = max(0, v - a.half), v1 = min(a.h - 1, v + a.half), u0 = max(0, u - a.half), u1 = min(a.w - 1, u + a.half);
+            for (int sv = v0; sv <= v1; ++sv)
+                for (int su = u0; su <= u1; ++su) {
+                    const int64_t q = (int64_t)sv * a.w + su;
+                    if (status[q] != PD_SEED || prio[q] >= best_prio) continue;
+                    if (accepts_px(pts, nrm, q, p, a)) { best = (int)q; best_prio = prio[q]; }
+                }
+        }
+        owner[p] = best;
+    }
+}
+
 inline int blocks_for(int64_t n) { int64_t b = (n + PB - 1) / PB; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
 struct patch_layout { size_t count, start, cursor, bucket, odd, nodd, temp, total; };
@@ -147,5 +209,30 @@ hipError_t f3d_launch_patch_owner(const int32_t* uv, int64_t m, int h, int w, in
     if (m > 0) hipLaunchKernelGGL(k_patch_fill, dim3(blocks_for(m)), dim3(PB), 0, s, uv, m, a, start, cursor, bucket);
     hipLaunchKernelGGL(k_patch_owner, dim3(blocks_for(npx)), dim3(PB), 0, s, uv, m, a, start, bucket, odd, nodd, seed_pts, seed_nrm, q_pts,
                        q_nrm, free_px, owner);
+    return hipGetLastError();
+}
+
+// patch_downsample: status (seed / claimed / not free) by rounds, then the owners.  `status` and `counter` are device scratch;
+// returns through *rounds the number of passes it took (diagnostic).
+hipError_t f3d_launch_patch_seeds(const double* pts, const double* nrm, const int32_t* prio, const uint8_t* free_px, int h, int w, int half,
+                                  double radius, double min_cosine, int32_t* status, int32_t* owner, int32_t* counter, int* rounds,
+                                  hipStream_t s) {
+    const int64_t npx = (int64_t)h * w;
+    *rounds = 0;
+    if (npx <= 0) return hipSuccess;
+    patch_args a; a.h = h; a.w = w; a.half = half; a.radius = radius; a.min_cosine = min_cosine;
+    const dim3 g(blocks_for(npx)), b(PB);
+    hipLaunchKernelGGL(k_pd_init, g, b, 0, s, free_px, npx, status);
+    for (int r = 0; r < (int)(npx < 1000000 ? npx + 2 : 1000002); ++r) {        // every pass resolves at least the earliest undecided pixel
+        hipError_t e = hipMemsetAsync(counter, 0, 4, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_pd_round, g, b, 0, s, pts, nrm, prio, a, status, counter);
+        int32_t left = 0;
+        if ((e = hipMemcpyAsync(&left, counter, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        *rounds = r + 1;
+        if (left == 0) break;
+    }
+    hipLaunchKernelGGL(k_pd_owner, g, b, 0, s, pts, nrm, prio, a, status, owner);
     return hipGetLastError();
 }

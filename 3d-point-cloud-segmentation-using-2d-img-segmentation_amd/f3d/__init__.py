@@ -102,6 +102,7 @@ def library():
         'f3d_components_same_class_dev': (i32, [vp, vp, i64, vp, vp, vp, vp, vp]),
         'f3d_patch_owner': (i32, [vp, vp, i64, i32, i32, i32, dbl, dbl, vp, vp, vp, vp, vp, vp]),
         'f3d_patch_owner_dev': (i32, [vp, vp, i64, i32, i32, i32, dbl, dbl, vp, vp, vp, vp, vp, vp, vp]),
+        'f3d_patch_seeds': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, dbl, dbl, vp, vp]),
         'f3d_unproject_depth': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp]),
         'f3d_unproject_depth_dev': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp, vp]),
         'f3d_radius_graph_count': (i32, [vp, vp, i32, i64, dbl, vp, vp]),
@@ -416,6 +417,19 @@ class Context:
         self._check(self._lib.f3d_patch_owner(self._h, _ptr(uv), m, h, w, int(half), float(radius), float(min_cosine), _ptr(sp), _ptr(sn),
                                               _ptr(qp), _ptr(qn), _ptr(fr), _ptr(owner)))
         return owner
+
+    def patch_seeds(self, frame_pts, frame_normals, prio, free, h, w, half, radius, min_cosine):
+        """Fusion.patch_downsample's seeds and what they take: owner int32 [h*w] (seed pixel index, -1 = nobody), rounds."""
+        qp, qn = _f64(frame_pts, (h * w, 3)), _f64(frame_normals, (h * w, 3))
+        pr = np.ascontiguousarray(prio, dtype=np.int32).reshape(-1)
+        fr = np.ascontiguousarray(free, dtype=np.uint8).reshape(-1)
+        if len(pr) != h * w or len(fr) != h * w:
+            raise ValueError('patch_seeds: prio and free must have h*w entries')
+        owner = np.empty(h * w, np.int32)
+        rounds = C.c_int32(0)
+        self._check(self._lib.f3d_patch_seeds(self._h, _ptr(qp), _ptr(qn), _ptr(pr), _ptr(fr), h, w, int(half), float(radius), float(min_cosine),
+                                              _ptr(owner), C.byref(rounds)))
+        return owner, rounds.value
 
     def unproject_depth(self, depth, K, q_wxyz, t, depth_scale=1000.0):
         """Depth frame [H,W] (uint16, float32 or float64) -> world points float64 [H*W,3] (ios_rtab.py:171-173,187-192)."""

@@ -295,6 +295,14 @@ int f3d_patch_owner_dev(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w
                         double min_cosine, const double* seed_pts, const double* seed_normals, const double* frame_pts,
                         const double* frame_normals, const uint8_t* free_px, int32_t* owner, void* stream);
 
+/* Fusion.patch_downsample (fusion.py:172-208): the pixels are visited in a shuffled order (prio[p] = position of pixel p); a
+ * pixel that is still free becomes a seed and takes the free pixels of its window that pass the same test.  owner[p] = the
+ * pixel index of the seed that takes p (a seed owns itself), -1 for pixels nobody takes; seeds are the pixels with
+ * owner[p] == p, in ascending prio.  Resolved in data-parallel rounds (*rounds, diagnostic).  Host pointers. */
+int f3d_patch_seeds(f3d_ctx* ctx, const double* frame_pts, const double* frame_normals, const int32_t* prio,
+                    const uint8_t* free_px, int h, int w, int half, double radius, double min_cosine,
+                    int32_t* owner, int32_t* rounds);
+
 /* ---- (f)#3: depth frame -> world points (RTAB_utils/ios_rtab.py) -------------------------- */
 /* RTAB2Cache.__getRGBP3d (:171-173): x = (px - cx) * (d / fx), y = (py - cy) * (d / fy), z = d with the scaled
  * intrinsics K and the integer pixel grid; __getModP3d: divided by depth_scale (1000: mm -> m, :187), rotated by the

@@ -102,8 +102,11 @@ def test_patch_downsample_and_frame_reader_match_reference_golden(golden, tmp_pa
     np.random.seed(int(g['c0_params'][5]))
     pcdimg = np.arange(h * w).reshape(h, w)
     pt2u, pt2v = (np.arange(h * w) % w).astype(np.int32), (np.arange(h * w) // w).astype(np.int32)
-    pts, nrm, clr, uv2pt, nmerges = Fusion.patch_downsample(g['points'][0], g['normals'][0], g['colors'][0], h, w, 10, 0.05,
-                                                            np.cos(np.deg2rad(10)), pcdimg, pt2u, pt2v, g['valid'][0].copy().reshape(h, w))
+    order = np.arange(h * w)
+    np.random.shuffle(order)                 # the sequential form (the public patch_downsample runs the HIP kernels: GPU tests)
+    pts, nrm, clr, uv2pt, nmerges = Fusion._patch_downsample_sequential(order, g['points'][0], g['normals'][0], g['colors'][0], h, w, 5, 0.05,
+                                                                        np.cos(np.deg2rad(10)), pcdimg, pt2u, pt2v,
+                                                                        g['valid'][0].copy().reshape(h, w))
     assert uv2pt.dtype == np.int32 and np.array_equal(uv2pt, g['c0_uv2pt'][0])
     assert len(pts) == len(nrm) == len(clr) == len(nmerges) == uv2pt.max() + 1 and nmerges.sum() == (uv2pt >= 0).sum()
     merged = _write_capture(tmp_path, g, 2)

@@ -421,6 +421,40 @@ def test_patch_owner_kernel_matches_the_sequential_matching_loop():
                                           free.reshape(-1), h, w, half, 0.1, 0.5), np.full(h * w, -1, np.int32))
 
 
+def test_patch_downsample_rounds_match_the_sequential_order_of_events():
+    """Fusion.patch_downsample (HIP seed resolution in rounds + ordered sums) against the literal visiting loop on random
+    frames: same seeds, members, means, lookups and the same consumption of the global generator."""
+    from Fusion3DSeg.fusion import Fusion
+    rng = np.random.default_rng(43)
+    for trial, (h, w, stride) in enumerate([(24, 32, 10), (17, 29, 4), (40, 40, 20), (9, 9, 1)]):
+        n = h * w
+        pts = np.stack(np.meshgrid(np.arange(w) * 0.03, np.arange(h) * 0.03), -1).reshape(-1, 2)
+        pts = np.concatenate([pts, rng.normal(0, 0.01, (n, 1)) + (np.arange(n)[:, None] % 7 == 0) * 0.2], 1)
+        nrm = rng.normal(0, 0.15, (n, 3)) + [0, 0, 1]; nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        clr = rng.uniform(0, 1, (n, 3))
+        free0 = rng.random((h, w)) < 0.9
+        pcdimg = np.arange(n).reshape(h, w)
+        pt2u, pt2v = (np.arange(n) % w).astype(np.int32), (np.arange(n) // w).astype(np.int32)
+        np.random.seed(100 + trial)
+        fa = free0.copy()
+        got = Fusion.patch_downsample(pts, nrm, clr, h, w, stride, 0.07, np.cos(np.deg2rad(20)), pcdimg, pt2u, pt2v, fa)
+        after_a = np.random.random()
+        np.random.seed(100 + trial)
+        order = np.arange(n); np.random.shuffle(order)
+        fb = free0.copy()
+        want = Fusion._patch_downsample_sequential(order, pts, nrm, clr, h, w, stride // 2, 0.07, np.cos(np.deg2rad(20)), pcdimg, pt2u, pt2v, fb)
+        assert np.random.random() == after_a                              # one shuffle each
+        for a, b in zip(got, want):
+            assert a.dtype == b.dtype and np.array_equal(a, b), trial
+        assert np.array_equal(fa, fb) and len(got[0]) > 3
+    # a free pixel with a zero normal does not accept itself: handled in the reference's own order of events
+    nrm[5] = 0.0
+    np.random.seed(7)
+    with np.errstate(all='ignore'):
+        z = Fusion.patch_downsample(pts, nrm, clr, h, w, 3, 0.07, 0.9, pcdimg, pt2u, pt2v, np.ones((h, w), bool))
+    assert len(z[0]) == len(z[4])
+
+
 def test_process3dseg_end_to_end_from_capture_files(golden, tmp_path):
     """process3D.py:14-68 on a capture written to disk: same cloud as the in-memory run, fusion directory complete."""
     from test_mirror_cpu import _write_capture
