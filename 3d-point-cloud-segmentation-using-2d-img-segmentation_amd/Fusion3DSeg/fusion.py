@@ -96,6 +96,24 @@ class FrameData:
         return str(d['frameNumber']), pts, np.array(d['modSurfaceNormals']), np.array(d['orgColorPoints']), ok
 
 
+def _row_norms(rows):
+    """np.linalg.norm(v) of every row, with the bits of the reference's per-vector call: for a 1-D vector NumPy takes
+    sqrt(v.dot(v)), and that dot is BLAS ddot (FMA, kernel dependent), unlike the axis=-1 form.  ``np.vecdot`` runs the same
+    kernel on the builds seen so far; it is used for large inputs only after it reproduced the per-vector results on the first
+    rows of THIS input."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    head = min(len(rows), 1024)
+    sq = np.empty(len(rows))
+    sq[:head] = [v.dot(v) for v in rows[:head]]
+    if head < len(rows):
+        fast = getattr(np, 'vecdot', None)
+        if fast is not None and np.array_equal(fast(rows[:head], rows[:head]), sq[:head]):
+            sq[head:] = fast(rows[head:], rows[head:])
+        else:
+            sq[head:] = [v.dot(v) for v in rows[head:]]
+    return np.sqrt(sq)
+
+
 def _mergeable(seed_pt, seed_normal, cand_pts, cand_normals, max_distance, min_cosine):
     """The reference's merge criterion (:165-170, :223-228): closer than max_distance AND normals within the angle."""
     near = np.linalg.norm(cand_pts - seed_pt[None, :], axis=-1) < max_distance
@@ -184,7 +202,7 @@ class Fusion:
 
         colors = np.asarray(colors)
         out_p, out_c, nsum = mean_in_order(points[members]), mean_in_order(colors[members]), mean_in_order(normals[members])
-        out_n = nsum / np.array([np.linalg.norm(v) for v in nsum])[:, None]  # one ddot per vector: the reference's bits
+        out_n = nsum / _row_norms(nsum)[:, None]
         uv2pt[members] = np.repeat(np.arange(len(first), dtype=np.int32), n_take)
         free[pt2v[members], pt2u[members]] = False
         return out_p, out_n, out_c, uv2pt, n_take
@@ -272,9 +290,7 @@ class Fusion:
                     x_pts[seeds] = (sum_in_order(q_pts[members]) + x_pts[seeds]) / denom
                     x_clr[seeds] = (sum_in_order(q_clr[members]) + x_clr[seeds]) / denom
                     nsum = (sum_in_order(q_nrm[members]) + x_nrm[seeds]) / denom
-                    # np.linalg.norm of ONE vector goes through BLAS ddot (FMA, kernel dependent), unlike the axis=-1 form:
-                    # taken per vector so that the bits are the reference's
-                    x_nrm[seeds] = nsum / np.array([np.linalg.norm(v) for v in nsum])[:, None]
+                    x_nrm[seeds] = nsum / _row_norms(nsum)[:, None]
                     x_mrg[seeds] += n_take
                     x_occ[seeds] += 1
                     uv2pt[members] = ids[seed_of]
