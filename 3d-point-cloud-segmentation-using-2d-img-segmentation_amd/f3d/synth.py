@@ -83,3 +83,25 @@ def scene(name, n=None, mask_kind='block64', dtype=np.float64):
     q, t = ring_views(cfg['views'])
     return dict(points=cloud(n, dtype=dtype), K=cfg['K'], w=cfg['w'], h=cfg['h'], wxyzs=q, translations=t,
                 masks=masks(cfg['views'], cfg['h'], cfg['w'], mask_kind), max_depth=10.0, nclasses=133)
+
+
+def depth_sequence(h=192, w=256, nframes=6, focal=210.0, step=0.15, seed=7):
+    """A capture for Fusion.fuse: a wall at z = 2.5 m and a floor seen by a camera that slides along x (axes = world axes).
+    Returns K, wxyz [F,4], t [F,3] and per frame world points, normals, colours [h*w,3] and a validity mask [h*w]."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[focal, 0.0, w / 2.0], [0.0, focal, h / 2.0], [0.0, 0.0, 1.0]])
+    q = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (nframes, 1))
+    t = np.stack([np.array([step * j, 0.0, 0.0]) for j in range(nframes)])
+    uu, vv = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    dirx, diry = (uu - K[0, 2]) / K[0, 0], (vv - K[1, 2]) / K[1, 1]
+    frames = []
+    for j in range(nframes):
+        with np.errstate(divide='ignore'):
+            z_floor = np.where(diry > 1e-9, 0.6 / diry, np.inf)
+        z = np.minimum(2.5, z_floor) + rng.normal(0, 0.002, (h, w))
+        cam = np.stack([dirx * z, diry * z, z], -1).reshape(-1, 3)
+        nrm = np.where((z_floor < 2.5).reshape(-1, 1), np.array([0.0, -1.0, 0.0]), np.array([0.0, 0.0, -1.0]))
+        valid = np.ones(h * w, bool)
+        valid[rng.integers(0, h * w, h * w // 30)] = False
+        frames.append((str(j), cam + t[j], nrm, rng.uniform(0, 1, (h * w, 3)), valid))
+    return K, q, t, frames
