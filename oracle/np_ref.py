@@ -301,9 +301,11 @@ def sem_logits_to_mask(sem, conf_threshold=0.017, unclassified=133):
     """get2DSeg.py:110-118: argmax over classes; softmax-max < conf_threshold -> 133.
 
     float32 arithmetic like torch's softmax: exp(x - max) / sum; the maximum
-    probability is 1 / sum(exp(x - max)).  torch is not run by the reference
-    here (detectron2/OneFormer absent): parity unpinned; the comparison uses a
-    tolerance band around the threshold.
+    probability is 1 / sum(exp(x - max)).  Pinned by tests/golden/sem_mask.npz:
+    the reference's own six statements run with CPU torch
+    (tests/golden/make_golden_sem.py); labels are equal outside a 1e-5 relative
+    band around the threshold (summation order of the 133 exponentials).  The
+    network that produces the logits is third-party and absent.
     """
     sem = np.asarray(sem, np.float32)
     lab = sem.argmax(0).astype(np.int64)

@@ -176,3 +176,32 @@ def test_unproject_depth_matches_reference_getModP3d(golden):
         got = O.unproject_depth(d, g['K'], q[[3, 0, 1, 2]], t)
         scale = np.dot(q, q) * np.abs(orig / 1000).max() + np.abs(t).max()
         assert np.abs(got - want).max() <= 8 * np.finfo(float).eps * scale
+
+
+SEM_CASES = ('img', 'edge', 'tie', 'tie0', 'tie5', 'small')
+SEM_BAND = 1e-5            # relative half-width of the band around conf_threshold that is not compared (see below)
+
+
+def sem_compare(got, g, name):
+    """`got` against the reference's own post-processing (tests/golden/make_golden_sem.py ran get2DSeg.py:111-120 with
+    CPU torch).  Labels must be EQUAL wherever torch's float32 max-probability is farther than SEM_BAND * threshold from
+    the threshold: the restatement and the HIP kernel sum the exponentials in another order (and the kernel uses
+    v_exp_f32), about 1e-6 relative on the probability, so only a pixel that close to the threshold may differ."""
+    want, pmax, thr = g[f'{name}_mask'], g[f'{name}_pmax'], float(g[f'{name}_conf'])
+    band = (np.abs(pmax.astype(np.float64) - thr) <= SEM_BAND * thr) if thr else np.zeros(want.shape, bool)
+    assert band.mean() < 1e-3, name                                   # the band is (nearly) empty: the comparison is not vacuous
+    assert np.array_equal(np.asarray(got, np.int64)[~band], want[~band]), name
+    return band
+
+
+def test_sem_logits_to_mask_matches_torch_reference(golden):
+    g = golden('sem_mask')
+    for name in SEM_CASES:
+        thr = float(g[f'{name}_conf'])
+        sem_compare(O.sem_logits_to_mask(g[f'{name}_sem'], thr, 133), g, name)
+    # the fixture really exercises the cases it is named for
+    assert (g['tie0_mask'][0] == 7).all() and (g['tie0_mask'][1] == 0).all() and (g['tie0_mask'][2] == 0).all()
+    assert (g['tie_mask'][1] == 133).all() and (g['tie5_mask'][1] == 1).all()
+    rel = np.abs(g['edge_pmax'].astype(np.float64) - 0.017) / 0.017
+    assert rel.min() > 2 * SEM_BAND and (rel < 2e-4).mean() > 0.3     # straddlers just outside the band, on both sides
+    assert 0.3 < (g['edge_mask'] == 133).mean() < 0.7
