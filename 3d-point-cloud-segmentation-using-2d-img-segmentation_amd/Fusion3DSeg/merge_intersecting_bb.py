@@ -50,6 +50,41 @@ def _pack(boxes):
     return np.array([np.concatenate([c, np.asarray(R).reshape(-1), e]) for c, R, e in boxes], np.float64).reshape(-1, 15)
 
 
+def cal_min_max(id, id_info_per_point, pcd_points, box_fn=None):
+    """Dead code of the reference (:15-42), kept for importers: the extents of instance `id`'s oriented-box corners along
+    the world axes.  The reference projects the 8 corners on the three axis lines with skspatial's ``Line.project_point``
+    (= the corner with the other two coordinates zeroed), takes the column-wise min / max and then drops the ZERO entries
+    (:24-25 -- a bug: an extent that is exactly 0 disappears as well); each of the six results is therefore an array of
+    0 or 1 elements.  skspatial and Open3D are absent from the image: restated, parity unpinned."""
+    pts = np.asarray(pcd_points)[np.where(id_info_per_point == id)]
+    corners = obb_corners(*(box_fn or obb_from_points)(pts))
+    out = []
+    for axis in range(3):
+        proj = np.zeros((8, 3))
+        proj[:, axis] = corners[:, axis]
+        mn, mx = proj.min(axis=0), proj.max(axis=0)
+        out += [mn[np.nonzero(mn)], mx[np.nonzero(mx)]]
+    return tuple(out)
+
+
+def check_intersection(id1, id_list, id_info_per_point, pcd_points, info_sem, box_fn=None):
+    """Dead code of the reference (:44-56): axis-interval overlap of the boxes of id1 and every id2 of the same
+    ``category_id``.  Quirks kept: the result list is re-created inside the loop (:48), so only the LAST id2 can be
+    reported; instance ids are looked up through ``id_list`` here (unlike check_intersection_open3d)."""
+    min_x1, max_x1, min_y1, max_y1, min_z1, max_z1 = cal_min_max(id_list[id1], id_info_per_point, pcd_points, box_fn)
+    intersecting_id = []
+    for id2 in range(1, len(id_list)):
+        if id1 != id2:
+            intersecting_id = []
+            if info_sem[id1]["category_id"] == info_sem[id2]["category_id"]:
+                min_x2, max_x2, min_y2, max_y2, min_z2, max_z2 = cal_min_max(id_list[id2], id_info_per_point, pcd_points, box_fn)
+                if (((min_x1 <= min_x2 and min_x2 <= max_x1) or (min_x2 <= min_x1 and min_x1 <= max_x2)) and
+                        ((min_y1 <= min_y2 and min_y2 <= max_y1) or (min_y2 <= min_y1 and min_y1 <= max_y2)) and
+                        ((min_z1 <= min_z2 and min_z2 <= max_z1) or (min_z2 <= min_z1 and min_z1 <= max_z2))):
+                    intersecting_id.append(id2)
+    return intersecting_id
+
+
 def intersection_point_bb(lst1, lst2):
     s = set(lst2)
     return [v for v in lst1 if v in s]

@@ -32,7 +32,9 @@ struct f3d_ctx {
     char err[512];
     void* slot[SLOT_COUNT];
     size_t cap[SLOT_COUNT];
-    int* dev_err;                       // sticky device error word
+    int* dev_err;                       // sticky device error word: one bit per operation (F3D_DEVERR_*)
+    int strict;                         // 1: a scratch buffer that would have to grow is F3D_ERR_NOMEM (allocation-free _dev calls)
+    long long allocs;                   // device allocations made by this context so far (f3d_ctx_alloc_count)
     unsigned long long* table;          // open-addressing set of the uv2pt vote
     size_t table_slots;
     int* filter_dev;                    // filter_classes lists longer than 8
@@ -65,10 +67,13 @@ int fail(f3d_ctx* ctx, int code, const char* fmt, ...) {
 int ensure(f3d_ctx* ctx, int s, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
     if (ctx->cap[s] < bytes) {
+        if (ctx->strict)
+            return fail(ctx, F3D_ERR_NOMEM, "strict context: scratch slot %d holds %zu bytes, %zu needed (f3d_ctx_reserve first)", s, ctx->cap[s], bytes);
         if (ctx->slot[s]) { F3D_HIP(ctx, hipFree(ctx->slot[s])); ctx->slot[s] = nullptr; ctx->cap[s] = 0; }
         size_t want = bytes + bytes / 8;
         F3D_HIP(ctx, hipMalloc(&ctx->slot[s], want));
         ctx->cap[s] = want;
+        ++ctx->allocs;
     }
     *out = ctx->slot[s];
     return F3D_OK;
@@ -111,14 +116,22 @@ int make_filter(f3d_ctx* ctx, const int32_t* filter, int nfilter, int ncols, boo
     return F3D_OK;
 }
 
-int take_error(f3d_ctx* ctx, hipStream_t s) {
+// Reads the sticky device error word and consumes the bits in `mask` (each operation owns one bit, so that an error
+// recorded by one operation is never blamed on, or silently skips, another one that shares the context).
+int take_error(f3d_ctx* ctx, hipStream_t s, int mask = F3D_DEVERR_ALL) {
     int e = 0;
     F3D_HIP(ctx, hipMemcpyAsync(&e, ctx->dev_err, sizeof(int), hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
+    e &= mask;
     if (e) {
-        F3D_HIP(ctx, hipMemsetAsync(ctx->dev_err, 0, sizeof(int), s));
+        F3D_HIP(ctx, f3d_launch_clear_error_bits(ctx->dev_err, e, s));
         F3D_HIP(ctx, hipStreamSynchronize(s));
-        if (e & F3D_DEVERR_INDEX) return fail(ctx, F3D_ERR_INDEX, "index out of bounds (the reference raises IndexError at voting.py:98)");
+        if (e & F3D_DEVERR_FUSE)
+            return fail(ctx, F3D_ERR_INDEX, "project_vote_argmax: a sampled mask label exceeds nclasses (the reference raises IndexError at voting.py:98)");
+        if (e & F3D_DEVERR_VOTE)
+            return fail(ctx, F3D_ERR_INDEX, "vote_uv2pt: point index or mask label out of bounds (the reference raises IndexError at voting.py:98)");
+        if (e & F3D_DEVERR_CC)
+            return fail(ctx, F3D_ERR_INDEX, "components_same_class: neighbour index out of bounds");
     }
     return F3D_OK;
 }
@@ -177,6 +190,8 @@ int quat_inverse(const double q[4], double o[4]) {
 
 }  // namespace
 
+static int ensure_table(f3d_ctx* ctx, int64_t hw);
+
 extern "C" {
 
 int f3d_version(void) { return F3D_VERSION; }
@@ -230,6 +245,31 @@ int f3d_ctx_synchronize(f3d_ctx* ctx) {
 }
 
 void* f3d_ctx_stream(f3d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+static size_t fuse_todo_bytes(int64_t n) { return 16 + (size_t)n * 4; }
+
+int f3d_ctx_reserve(f3d_ctx* ctx, int64_t n, int nviews, int h, int w) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || n > 0x7fffffffLL || nviews < 0 || h < 0 || w < 0) return fail(ctx, F3D_ERR_INVALID, "ctx_reserve: bad arguments");
+    const int strict = ctx->strict;
+    ctx->strict = 0;
+    void* p;
+    rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &p);
+    if (!rc && n > 0) rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &p);
+    if (!rc && n > 0) rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &p);
+    if (!rc && nviews > 0 && h > 0 && w > 0) rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &p);
+    if (!rc && h > 0 && w > 0) rc = ensure_table(ctx, (int64_t)h * w);
+    ctx->strict = strict;
+    return rc;
+}
+
+int f3d_ctx_set_strict(f3d_ctx* ctx, int strict) {
+    if (!ctx) return F3D_ERR_INVALID;
+    ctx->strict = strict ? 1 : 0;
+    return F3D_OK;
+}
+
+long long f3d_ctx_alloc_count(const f3d_ctx* ctx) { return ctx ? ctx->allocs : -1; }
 
 // ---------------------------------------------------------------------------------------------
 // host geometry
@@ -499,7 +539,7 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
         cmasks = (const uint8_t*)tm;
     }
     void* todo;                                                                                 // grows on first use only
-    if ((rc = ensure(ctx, SLOT_TODO, 16 + (size_t)n * 4, &todo))) return rc;
+    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,
                                  ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), s));
     return F3D_OK;
@@ -554,7 +594,7 @@ int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
                                           nclasses, filter, nfilter, threshold, (int64_t*)dcls, (uint16_t*)dvotes, flags,
                                           nullptr, s)))
         return rc;
-    if ((rc = take_error(ctx, s))) return rc;
+    if ((rc = take_error(ctx, s, F3D_DEVERR_FUSE))) return rc;
     F3D_HIP(ctx, hipMemcpyAsync(classes, dcls, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     if (votes_u16) F3D_HIP(ctx, hipMemcpyAsync(votes_u16, dvotes, (size_t)n * ncols * 2, hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
@@ -568,9 +608,11 @@ static int ensure_table(f3d_ctx* ctx, int64_t hw) {
     size_t want = 1024;
     while (want < (size_t)hw * 2) want <<= 1;
     if (ctx->table_slots < want) {
+        if (ctx->strict) return fail(ctx, F3D_ERR_NOMEM, "strict context: the vote table holds %zu slots, %zu needed (f3d_ctx_reserve first)", ctx->table_slots, want);
         if (ctx->table) { F3D_HIP(ctx, hipFree(ctx->table)); ctx->table = nullptr; ctx->table_slots = 0; }
         F3D_HIP(ctx, hipMalloc((void**)&ctx->table, want * sizeof(unsigned long long)));
         ctx->table_slots = want;
+        ++ctx->allocs;
     }
     return F3D_OK;
 }
@@ -603,7 +645,7 @@ int f3d_vote_uv2pt(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int6
     F3D_HIP(ctx, hipMemcpyAsync(dmask, mask, (size_t)hw, hipMemcpyHostToDevice, s));
     F3D_HIP(ctx, hipMemcpyAsync(dvotes, votes, vbytes, hipMemcpyHostToDevice, s));
     if ((rc = f3d_vote_uv2pt_dev(ctx, (const int32_t*)dlut, (const uint8_t*)dmask, hw, (double*)dvotes, npts, ncols, s))) return rc;
-    if ((rc = take_error(ctx, s))) return rc;                 // nothing was written in that case
+    if ((rc = take_error(ctx, s, F3D_DEVERR_VOTE))) return rc;   // nothing was written in that case
     F3D_HIP(ctx, hipMemcpyAsync(votes, dvotes, vbytes, hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
     return F3D_OK;
@@ -862,7 +904,7 @@ int f3d_components_same_class(f3d_ctx* ctx, const int64_t* classes, int64_t n, c
     if (e) F3D_HIP(ctx, hipMemcpyAsync(dnb, nbrs, (size_t)e * 4, hipMemcpyHostToDevice, s));
     if ((rc = f3d_components_same_class_dev(ctx, (const int64_t*)dcls, n, (const int64_t*)doffs, (const int32_t*)dnb, (int32_t*)dpar,
                                             (int64_t*)droot, s))) return rc;
-    if ((rc = take_error(ctx, s))) return rc;
+    if ((rc = take_error(ctx, s, F3D_DEVERR_CC))) return rc;
     F3D_HIP(ctx, hipMemcpyAsync(root, droot, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
     return F3D_OK;

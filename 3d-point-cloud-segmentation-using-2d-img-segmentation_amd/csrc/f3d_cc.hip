@@ -38,7 +38,7 @@ __global__ __launch_bounds__(CB) void k_cc_hook(const int64_t* __restrict__ clas
         const int64_t ci = classes[i];
         for (int64_t e = offs[i]; e < offs[i + 1]; ++e) {
             const int64_t j = nbrs[e];
-            if (j < 0 || j >= n) { atomicOr(err, F3D_DEVERR_INDEX); continue; }
+            if (j < 0 || j >= n) { atomicOr(err, F3D_DEVERR_CC); continue; }
             if (j == i || classes[j] != ci) continue;
             int32_t a = (int32_t)i, b = (int32_t)j;
             for (;;) {

@@ -4,7 +4,12 @@
 #include <stdint.h>
 #include "f3d.h"
 
-#define F3D_DEVERR_INDEX 1                 // sticky device error bit: the reference would raise IndexError
+// sticky device error word of a context: one bit per operation, so that an IndexError recorded by one operation is
+// neither blamed on nor silently skips another one that shares the context
+#define F3D_DEVERR_FUSE 1                  // project_vote_argmax: a sampled label > nclasses (voting.py:98)
+#define F3D_DEVERR_VOTE 2                  // vote_uv2pt: point index or label out of bounds (voting.py:98)
+#define F3D_DEVERR_CC 4                    // components_same_class: neighbour index out of bounds
+#define F3D_DEVERR_ALL 7
 #define F3D_PLANES_PER_LAUNCH 16
 #define F3D_OBB_MAX_BOXES 4096
 #define F3D_SORT_MAX_CELLS 32767            // + 1 overflow cell = 2^15 keys -> 16 key bits sorted
@@ -37,6 +42,7 @@ struct f3d_filter_args {                   // filter_classes of VotingSegmentati
     const int* cls_dev;                    // device copy of the list when nfilter > 8
 };
 
+hipError_t f3d_launch_clear_error_bits(int* err, int bits, hipStream_t s);
 hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], double* out, hipStream_t s);
 hipError_t f3d_launch_unproject_depth(const void* depth, int depth_type, int h, int w, const double K[9], double scale,
                                       const double q[4], const double t[3], double* out, hipStream_t s);

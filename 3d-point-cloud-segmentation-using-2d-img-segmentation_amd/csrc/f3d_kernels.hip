@@ -635,7 +635,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse(const T* __restrict__ xyz, i
         defer = defer | (live & ((st.best >> 16) >= 0xFFu));                               // an 8-bit bin overflowed (needs > 255 views)
         if (defer) todo[atomicAdd(todo_count, 1u)] = (int32_t)(gather_xyz ? orig : i);     // index into xyz as this launch sees it
         const bool bad = finish_coded<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live & !defer, orig, classes, votes_out);
-        if (bad & !defer) atomicOr(err, F3D_DEVERR_INDEX);
+        if (bad & !defer) atomicOr(err, F3D_DEVERR_FUSE);
     }
 }
 
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ 
             const int label = hit ? (int)(masks + (size_t)v * plane)[off] : 0;
             vote_add<MODE>(st, hist, tid, flt, nclasses, hit, label);
         }
-        if (st.bad) atomicOr(err, F3D_DEVERR_INDEX);
+        if (st.bad) atomicOr(err, F3D_DEVERR_FUSE);
         finish_point<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live, orig, classes, votes_out);
     }
 }
@@ -796,14 +796,14 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_vote_validate(const int32_t* __re
         if (p == -1) continue;
         if (p >= npts || p < -npts || (int)mask[i] >= ncols) bad = true;
     }
-    if (bad) atomicOr(err, F3D_DEVERR_INDEX);
+    if (bad) atomicOr(err, F3D_DEVERR_VOTE);
 }
 
 __global__ __launch_bounds__(F3D_BLOCK) void k_vote_uv2pt(const int32_t* __restrict__ uv2pt, const uint8_t* __restrict__ mask,
                                                            int64_t hw, double* __restrict__ votes, int64_t npts, int ncols,
                                                            unsigned long long* __restrict__ table, uint64_t table_mask,
                                                            const int* __restrict__ err) {
-    if (*err & F3D_DEVERR_INDEX) return;
+    if (*err & F3D_DEVERR_VOTE) return;
     for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < hw; i += (int64_t)gridDim.x * F3D_BLOCK) {
         int64_t p = uv2pt[i];
         if (p == -1) continue;
@@ -966,6 +966,8 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_relabel(int64_t* __restrict__ ids
     }
 }
 
+__global__ void k_clear_error_bits(int* err, int bits) { atomicAnd(err, ~bits); }
+
 inline int grid_for(int64_t n, int per_block, int cap) {
     int64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -982,6 +984,11 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 #ifndef F3D_FUSE_GRID
 #define F3D_FUSE_GRID (256 * 4 * 8)     // k_fuse: 4 resident blocks per CU (LDS limit), 8 rounds so that the tail stays short
 #endif
+
+hipError_t f3d_launch_clear_error_bits(int* err, int bits, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear_error_bits, dim3(1), dim3(1), 0, s, err, bits);
+    return hipGetLastError();
+}
 
 hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], double* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
@@ -1063,9 +1070,11 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     }
 #define F3D_FUSE(T, M, V)                                                                                      \
     do {                                                                                                       \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_fuse<T, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (lds_exact > 64 * 1024)                                                                             \
-            (void)hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact); \
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)k_fuse<T, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return hipErrorInvalidValue;                                                                       \
+        if (lds_exact > 48 * 1024 &&                                                                           \
+            hipFuncSetAttribute((const void*)k_fuse_exact<T, M, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact) != hipSuccess) \
+            return hipErrorInvalidValue;                                                                       \
         if (fast)                                                                                              \
             hipLaunchKernelGGL((k_fuse<T, V>), g, b, lds, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, \
                                nclasses, flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo); \
@@ -1145,11 +1154,18 @@ hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const
     }
     const size_t lds = (size_t)((b + 31) / 32) * F3D_BLOCK * sizeof(uint32_t);
     const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), blk(F3D_BLOCK);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (dtype == F3D_F64) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_in_obb<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) {                             // beyond the default dynamic-LDS limit: the launch needs the attribute
+            hipError_t e = hipFuncSetAttribute((const void*)k_points_in_obb<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(k_points_in_obb<double>, g, blk, lds, s, (const double*)xyz, n, boxes_dev, b, bits, cooc);
     } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_points_in_obb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_points_in_obb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(k_points_in_obb<float>, g, blk, lds, s, (const float*)xyz, n, boxes_dev, b, bits, cooc);
     }
     return hipGetLastError();

@@ -67,6 +67,9 @@ def library():
         'f3d_last_error': (C.c_char_p, [vp]),
         'f3d_ctx_synchronize': (i32, [vp]),
         'f3d_ctx_stream': (vp, [vp]),
+        'f3d_ctx_reserve': (i32, [vp, i64, i32, i32, i32]),
+        'f3d_ctx_set_strict': (i32, [vp, i32]),
+        'f3d_ctx_alloc_count': (C.c_longlong, [vp]),
         'f3d_quat_inverse': (i32, [vp, vp]),
         'f3d_frustum_data': (i32, [vp, dbl, dbl, vp, vp, i32, vp, vp, vp]),
         'f3d_views_build': (i32, [vp, dbl, dbl, vp, vp, i32, dbl, vp]),
@@ -238,6 +241,17 @@ class Context:
 
     def synchronize(self):
         self._check(self._lib.f3d_ctx_synchronize(self._h))
+
+    def reserve(self, n=0, nviews=0, h=0, w=0):
+        """Size the scratch of the fused path / cell sort / uv2pt vote beforehand: later _dev calls do not allocate."""
+        self._check(self._lib.f3d_ctx_reserve(self._h, int(n), int(nviews), int(h), int(w)))
+
+    def set_strict(self, strict=True):
+        self._check(self._lib.f3d_ctx_set_strict(self._h, int(bool(strict))))
+
+    @property
+    def alloc_count(self):
+        return int(self._lib.f3d_ctx_alloc_count(self._h))
 
     # ---------------------------------------------------------------- NumPy (host pointer) calls
     def rotate(self, points, q_wxyz):

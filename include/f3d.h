@@ -16,7 +16,11 @@
  *     through the context's scratch arena, the kernels run on the context's stream, outputs are
  *     copied back, and the call returns after the stream has drained (NumPy drop-in).
  *   - "_dev" functions take DEVICE pointers and a hipStream_t (as void*; NULL = the context's
- *     own stream).  They only enqueue work: no allocation, no synchronisation (hipGraph-safe).
+ *     own stream).  They only enqueue work and never synchronise.  Scratch (sort keys, coded masks,
+ *     the deferred-point list, the vote table) lives in the context and GROWS ON FIRST USE of a larger
+ *     problem (hipMalloc, not capturable); size it beforehand with f3d_ctx_reserve() and a _dev call
+ *     of that or a smaller size performs no allocation at all (hipGraph-safe).  With
+ *     f3d_ctx_set_strict(ctx, 1) a call that would have to grow scratch fails with F3D_ERR_NOMEM instead.
  *   - the caller owns every buffer; the library keeps no caller pointer after a call returns
  *     (host variants) / after the enqueued work has completed (_dev variants).
  *   - a context is not thread-safe; use one per thread.  There is no global state.
@@ -104,6 +108,13 @@ void        f3d_ctx_destroy(f3d_ctx* ctx);
 const char* f3d_last_error(const f3d_ctx* ctx);    /* ctx may be NULL: last creation error        */
 int         f3d_ctx_synchronize(f3d_ctx* ctx);
 void*       f3d_ctx_stream(f3d_ctx* ctx);          /* the context's hipStream_t                   */
+/* Sizes the context's scratch for f3d_project_vote_argmax_dev / f3d_cloud_sort_cells_dev on up to n points, nviews
+ * masks of h x w pixels, and for f3d_vote_uv2pt_dev frames of h*w pixels (any argument may be 0 to skip its part). */
+int         f3d_ctx_reserve(f3d_ctx* ctx, int64_t n, int nviews, int h, int w);
+/* strict = 1: scratch never grows inside a call; a too-small buffer is F3D_ERR_NOMEM (reserve first). */
+int         f3d_ctx_set_strict(f3d_ctx* ctx, int strict);
+/* Number of device allocations this context has made so far (diagnostic: unchanged across an allocation-free call). */
+long long   f3d_ctx_alloc_count(const f3d_ctx* ctx);
 
 /* ---- host-side geometry (tiny, per view; no device needed) ------------------------------ */
 /* pyquaternion Quaternion(q).inverse.elements at camera_utils.py:22 */
@@ -188,8 +199,9 @@ int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int
  * and, unless NULL, sorted_xyz (same dtype/size as xyz); device buffers owned by the caller. */
 int f3d_cloud_sort_cells_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
                              void* sorted_xyz, int32_t* perm, void* stream);
-/* Returns and clears the sticky error recorded by _dev kernels of this context
- * (F3D_OK or F3D_ERR_INDEX).  Synchronises the context's error word only. */
+/* Returns and clears the sticky error recorded by _dev kernels of this context (F3D_OK or F3D_ERR_INDEX; the
+ * message names the operation that recorded it: each operation owns one bit of the word, and the host-pointer
+ * variants consume only their own).  Synchronises `stream`. */
 int f3d_take_device_error(f3d_ctx* ctx, void* stream);
 
 /* ---- a7: one frame of VotingSegmentation.vote (voting.py:94-98) --------------------------- */

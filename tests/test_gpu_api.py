@@ -1,0 +1,151 @@
+"""C-ABI contract on a real device: allocation-free _dev calls after f3d_ctx_reserve, strict contexts, per-operation
+device error bits, the largest box counts of f3d_points_in_obb, and the point-sharded step with the HIP path under a
+two-rank process group (both ranks on device 0, gloo)."""
+import os
+
+import numpy as np
+import pytest
+
+import f3d
+from f3d import synth
+from oracle import np_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n=50_000):
+    sc = synth.scene('C1', n=n)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    return sc, views
+
+
+def test_reserved_context_does_not_allocate_and_strict_context_refuses_to():
+    import torch
+    dev = torch.device('cuda', 0)
+    sc, views = _scene()
+    n, (V, H, W) = len(sc['points']), sc['masks'].shape
+    x, vd, md = (torch.from_numpy(a).to(dev) for a in (sc['points'], views, sc['masks']))
+    cls = torch.empty(n, dtype=torch.int64, device=dev)
+    s = torch.cuda.Stream(dev)
+
+    def call(ctx, npts=n):
+        ctx.project_vote_argmax_dev(x.data_ptr(), f3d.F64, npts, vd.data_ptr(), V, md.data_ptr(), H, W, 133, 0.5, None,
+                                    cls.data_ptr(), None, s.cuda_stream, flags=f3d.FUSE_SORT)
+        s.synchronize()
+
+    ctx = f3d.Context(0)
+    ctx.reserve(n, V, H, W)
+    before = ctx.alloc_count
+    assert before > 0
+    call(ctx); call(ctx); call(ctx, n // 2)
+    assert ctx.alloc_count == before                       # no hipMalloc inside the calls
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'])
+    assert np.array_equal(cls.cpu().numpy()[:n // 2], want[:n // 2])
+    ctx.close()
+
+    strict = f3d.Context(0)
+    strict.set_strict(True)
+    with pytest.raises(MemoryError):
+        call(strict)                                       # nothing reserved: F3D_ERR_NOMEM instead of a hidden hipMalloc
+    strict.reserve(n, V, H, W)
+    call(strict)
+    assert np.array_equal(cls.cpu().numpy(), want)
+    taller = torch.zeros((V, 2 * H, W), dtype=torch.uint8, device=dev)
+    with pytest.raises(MemoryError):                       # a larger problem than reserved
+        strict.project_vote_argmax_dev(x.data_ptr(), f3d.F64, n, vd.data_ptr(), V, taller.data_ptr(), 2 * H, W, 133, 0.5, None,
+                                       cls.data_ptr(), None, s.cuda_stream, flags=0)
+    strict.close()
+
+    lazy = f3d.Context(0)                                  # the default: scratch grows on first use, then stays
+    call(lazy)
+    grown = lazy.alloc_count
+    call(lazy)
+    assert lazy.alloc_count == grown
+    lazy.close()
+
+
+def test_device_error_bits_belong_to_their_operation():
+    """A stale IndexError flag of the fused path must neither skip nor be blamed on a later uv2pt vote (and vice versa)."""
+    import torch
+    dev = torch.device('cuda', 0)
+    ctx = f3d.Context(0)
+    sc, views = _scene(5000)
+    bad = sc['masks'].copy(); bad[:] = 200
+    n, (V, H, W) = len(sc['points']), bad.shape
+    x, vd, md = (torch.from_numpy(a).to(dev) for a in (sc['points'], views, bad))
+    cls = torch.empty(n, dtype=torch.int64, device=dev)
+    s = torch.cuda.Stream(dev)
+    ctx.project_vote_argmax_dev(x.data_ptr(), f3d.F64, n, vd.data_ptr(), V, md.data_ptr(), H, W, 133, 0.5, None, cls.data_ptr(), None, s.cuda_stream)
+    s.synchronize()                                        # the fused error is now pending in the context, nobody has taken it
+    votes = np.zeros((6, 3))
+    ctx.vote_uv2pt(votes, np.array([0, 1, 5, 5], np.int32), np.array([0, 2, 1, 1], np.uint8))
+    assert votes.sum() == 3 and votes[5, 1] == 1           # the vote ran (it used to be skipped silently)
+    with pytest.raises(IndexError, match='vote_uv2pt'):
+        ctx.vote_uv2pt(votes, np.array([0, 9], np.int32), np.array([0, 0], np.uint8))
+    assert votes.sum() == 3
+    with pytest.raises(IndexError, match='project_vote_argmax'):
+        ctx.take_device_error(s.cuda_stream)
+    ctx.take_device_error(s.cuda_stream)                   # consumed
+    offs = np.array([0, 1, 2], np.int64)
+    with pytest.raises(IndexError, match='components_same_class'):
+        ctx.components_same_class(np.array([1, 1]), offs, np.array([1, 7], np.int32))
+    ctx.vote_uv2pt(votes, np.array([2], np.int32), np.array([2], np.uint8))
+    assert votes[2, 2] == 1
+    ctx.close()
+
+
+@pytest.mark.parametrize('B', [37, 2047, 4096])
+def test_points_in_obb_large_and_ragged_box_counts(B):
+    """Box counts that are not a multiple of 32 and the maximum of one call (4096 boxes = 128 KiB of LDS bitset per block,
+    beyond the default dynamic-LDS limit: the launch has to raise it and report a failure to do so)."""
+    ctx = f3d.default_context()
+    rng = np.random.default_rng(B)
+    pts = rng.uniform([-5, -5, 0], [5, 5, 3], (20_000, 3))
+    boxes = np.zeros((B, 15))
+    boxes[:, 0:3] = rng.uniform([-5, -5, 0], [5, 5, 3], (B, 3))
+    for k in range(B):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        boxes[k, 3:12] = q.reshape(-1)
+    boxes[:, 12:15] = rng.uniform(0.2, 0.9, (B, 3))
+    inside, cooc = ctx.points_in_obb(pts, boxes)
+    sel = rng.choice(B, 24, replace=False)
+    for k in sel:
+        assert np.array_equal(inside[:, k], O.points_in_obb(pts, boxes[k, 0:3], boxes[k, 3:12].reshape(3, 3), boxes[k, 12:15])), k
+    m = inside.astype(np.float32)
+    assert np.array_equal(cooc, (m.T @ m) > 0)
+    assert inside.any(0).mean() > 0.5
+
+
+def _rank_labels(rank, world, port, n, out_dir):
+    """One rank of the point-sharded step: HIP labels of its shard, masks all-gathered over the process group."""
+    import torch
+    import torch.distributed as dist
+    from f3d import sharding
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sc = synth.scene('C1', n=n)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    ctx = f3d.Context(0)
+    v0, v1 = sharding.view_bounds(len(views), rank, world)
+
+    def label_fn(points, masks_full):
+        return ctx.project_vote_argmax(points, views, masks_full.numpy(), 133, 0.0, None)
+
+    labels = sharding.sharded_labels(dist, sc['points'], torch.from_numpy(sc['masks'][v0:v1].copy()), label_fn, gather=True)
+    np.save(os.path.join(out_dir, f'labels{rank}.npy'), labels.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_label_their_shards_with_the_hip_path(tmp_path):
+    """world size 2 (two fresh processes, both on device 0, gloo): unequal shards (n odd), every rank's HIP labels gathered,
+    equal to the single-process HIP result and to the oracle."""
+    import torch.multiprocessing as mp
+    n = 40_001
+    mp.spawn(_rank_labels, args=(2, 29533, n, str(tmp_path)), nprocs=2, join=True)
+    sc, views = _scene(n)
+    single = f3d.default_context().project_vote_argmax(sc['points'], views, sc['masks'], 133, 0.0, None)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f'labels{r}.npy'), single), r
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.0, None)
+    assert np.array_equal(single, want) and (want != 133).mean() > 0.5

@@ -65,6 +65,24 @@ def test_obb_fit_contains_its_points_and_matches_oracle_recipe():
     assert e[0] >= e[1] >= e[2]
 
 
+def test_dead_aabb_overlap_pair_is_importable_and_keeps_its_quirks():
+    """cal_min_max / check_intersection (reference merge_intersecting_bb.py:15-56, dead code; skspatial absent -> unpinned):
+    axis extents of the box corners, the zero-dropping filter, and the result list that is reset inside the loop."""
+    from Fusion3DSeg.merge_intersecting_bb import cal_min_max, check_intersection, obb_corners, obb_from_points
+    rng = np.random.default_rng(4)
+    pts = np.vstack([rng.normal(size=(200, 3)) * [1.0, 0.4, 0.2] + c for c in ([3.0, 2.0, 1.0], [3.5, 2.2, 1.1], [30.0, 2.0, 1.0])])
+    ids = np.repeat([1, 2, 3], 200)
+    mn_x, mx_x, mn_y, mx_y, mn_z, mx_z = cal_min_max(1, ids, pts)
+    corners = obb_corners(*obb_from_points(pts[:200]))
+    assert mn_x.shape == (1,) and mn_x[0] == corners[:, 0].min() and mx_z[0] == corners[:, 2].max()
+    info = [{'category_id': 86}] * 4
+    id_list = [0, 1, 2, 3]
+    assert check_intersection(1, id_list, ids, pts, info) == []           # id2 = 3 is the last one looked at: far away
+    assert check_intersection(1, id_list[:3], ids, pts, info) == [2]      # now id2 = 2 is the last: boxes overlap
+    info2 = [{'category_id': 86}, {'category_id': 86}, {'category_id': 3}]
+    assert check_intersection(1, id_list[:3], ids, pts, info2) == []      # other category
+
+
 def test_load_csv(tmp_path):
     (tmp_path / 'classes.csv').write_text('Class_ID,Parent,Parent_ID,flag_infojson,flag_objremoval\n86,wall,1,1,0\n114,floor,2,1,0\n3,car,5,0,1\n')
     cid, pname, pid, fj, keep = get3DSeg.load_csv(tmp_path / 'classes.csv')
