@@ -11,6 +11,7 @@ reference; without it, ``obb_from_points`` below follows the same published reci
 hull vertices -> extents in that frame).  That fit is unpinned against Open3D.
 """
 import json
+import os
 import time
 from pathlib import Path
 
@@ -105,10 +106,14 @@ class _MergeState:
 
     def __init__(self, pts, ids, box_fn):
         self.pts, self.ids, self.box_fn = pts, ids, box_fn
+        self.prof = {'group': 0.0, 'fit': 0.0, 'nfit': 0, 'scan': 0.0, 'nscan': 0, 'absorb': 0.0, 'upload': 0.0}
+        t0 = time.perf_counter()
         order = np.argsort(ids, kind='stable')
         uniq, start = np.unique(ids[order], return_index=True)
         bounds = np.append(start, len(order))
         self.members = {int(u): order[bounds[k]:bounds[k + 1]] for k, u in enumerate(uniq)}
+        self.prof['group'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         self.boxes = {}
         self.ctx = f3d.default_context()
         self.dev = None
@@ -119,8 +124,10 @@ class _MergeState:
                 self.device = torch.device('cuda', self.ctx.device)
                 self.dev = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)).to(self.device)
                 self.stream = torch.cuda.Stream(self.device)
+                torch.cuda.synchronize(self.device)
         except ImportError:
             pass
+        self.prof['upload'] = time.perf_counter() - t0
 
     def count(self, i):
         m = self.members.get(int(i))
@@ -130,7 +137,9 @@ class _MergeState:
         """(center, R, extent, aabb_lo, aabb_hi) of instance i, refitted only after its membership changed."""
         i = int(i)
         if i not in self.boxes:
+            t0 = time.perf_counter()
             c, R, e = self.box_fn(self.pts[self.members[i]])
+            self.prof['fit'] += time.perf_counter() - t0; self.prof['nfit'] += 1
             corners = obb_corners(c, R, e)
             pad = 1e-9 * (np.abs(corners).max() + np.abs(e).max() + 1.0)       # the in-box test rounds; never prune a touching pair
             self.boxes[i] = (c, R, e, corners.min(0) - pad, corners.max(0) + pad)
@@ -139,6 +148,7 @@ class _MergeState:
     def absorb(self, dst, src):
         """update_id_info's relabel (reference :59-61) on the incremental state."""
         dst, src = int(dst), int(src)
+        t0 = time.perf_counter()
         moved = self.members.pop(src, None)
         if moved is None or not len(moved):
             return
@@ -147,10 +157,12 @@ class _MergeState:
         self.members[dst] = np.sort(moved) if cur is None else np.sort(np.concatenate([cur, moved]))
         self.boxes.pop(dst, None)
         self.boxes.pop(src, None)
+        self.prof['absorb'] += time.perf_counter() - t0
 
     def shares_point(self, box1, others):
         """For each box in `others`: does some cloud point lie in both it and box1?  One launch over the cloud."""
         hits = np.zeros(len(others), bool)
+        t0 = time.perf_counter()
         for s in range(0, len(others), f3d.MAX_OBB - 1):
             part = [box1] + others[s:s + f3d.MAX_OBB - 1]
             packed = _pack([(b[0], b[1], b[2]) for b in part])
@@ -165,6 +177,7 @@ class _MergeState:
                     self.stream.synchronize()
                     cooc = cd.cpu().numpy().astype(bool)
             hits[s:s + len(part) - 1] = cooc[0, 1:]
+        self.prof['scan'] += time.perf_counter() - t0; self.prof['nscan'] += 1
         return hits
 
 
@@ -214,6 +227,8 @@ def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=obb_from_points)
             c, R, e = st.box(i)[:3]
             info_sem[k]["bbox"] = obb_corners(c, R, e).tolist()
     print(f'Time taken for merging {n0} to {len(info_sem)} Bounding boxes = {time.perf_counter() - t0} seconds')
+    if os.environ.get('F3D_MERGE_PROFILE'):
+        print('merge_bb breakdown [s]: ' + ', '.join(f'{k}={v:.3f}' if isinstance(v, float) else f'{k}={v}' for k, v in st.prof.items()))
     if dir_name is not None:
         out = Path(dir_name) / "panoptic_segmentation"
         out.mkdir(parents=True, exist_ok=True)

@@ -3,6 +3,7 @@
 // needs a HIP device.
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <cstddef>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -13,7 +14,9 @@
 #include "f3d_kernels.h"
 #include "f3d_math.h"
 
-static_assert(sizeof(f3d_view) == 640, "f3d_view is 80 doubles");
+static_assert(sizeof(f3d_view) == 704, "f3d_view is 88 doubles");
+static_assert(offsetof(f3d_view, t) == 72 && offsetof(f3d_view, mnorm) == 96, "the kernels stage M, t, mnorm as the record's first 15 doubles");
+static_assert(offsetof(f3d_view, img_h) == offsetof(f3d_view, cull_n32) + 23 * 4, "cull planes, margins and image size: 24 consecutive floats");
 
 #pragma clang fp contract(off)
 
@@ -37,8 +40,10 @@ struct f3d_ctx {
     long long allocs;                   // device allocations made by this context so far (f3d_ctx_alloc_count)
     unsigned long long* table;          // open-addressing set of the uv2pt vote
     size_t table_slots;
-    int* filter_dev;                    // filter_classes lists longer than 8
+    int* filter_dev;                    // filter_classes of the call being enqueued (device copy)
+    int32_t filter_host[F3D_MAX_FILTER];  // its staging copy: must outlive the asynchronous upload
     unsigned long long* count_dev;
+    f3d_codebook* codebook;             // vote-bin code book of the fused path (device)
     // radius graph: the grid of the last count pass (the fill pass must follow it for the same cloud)
     f3d_graphgrid graph_grid;
     int64_t graph_n;
@@ -107,12 +112,11 @@ int make_filter(f3d_ctx* ctx, const int32_t* filter, int nfilter, int ncols, boo
     fa->nfilter = nfilter;
     int32_t tmp[F3D_MAX_FILTER];
     for (int k = 0; k < nfilter; ++k) tmp[k] = filter[k] < 0 ? filter[k] + ncols : filter[k];   // NumPy negative index
-    if (nfilter <= 8) {
-        for (int k = 0; k < nfilter; ++k) fa->cls[k] = tmp[k];
-    } else {
-        F3D_HIP(ctx, hipMemcpyAsync(ctx->filter_dev, tmp, sizeof(int32_t) * nfilter, hipMemcpyHostToDevice, s));
-        fa->cls_dev = ctx->filter_dev;
-    }
+    if (nfilter <= 8) for (int k = 0; k < nfilter; ++k) fa->cls[k] = tmp[k];
+    // the device copy always exists (the fused kernel reads the list from memory, whatever its length)
+    memcpy(ctx->filter_host, tmp, sizeof(int32_t) * nfilter);
+    F3D_HIP(ctx, hipMemcpyAsync(ctx->filter_dev, ctx->filter_host, sizeof(int32_t) * nfilter, hipMemcpyHostToDevice, s));
+    fa->cls_dev = ctx->filter_dev;
     return F3D_OK;
 }
 
@@ -214,6 +218,7 @@ f3d_ctx* f3d_ctx_create(int device) {
               hipMalloc((void**)&ctx->dev_err, sizeof(int)) == hipSuccess &&
               hipMalloc((void**)&ctx->filter_dev, sizeof(int32_t) * F3D_MAX_FILTER) == hipSuccess &&
               hipMalloc((void**)&ctx->count_dev, sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&ctx->codebook, sizeof(f3d_codebook)) == hipSuccess &&
               hipMemset(ctx->dev_err, 0, sizeof(int)) == hipSuccess;
     if (!ok) {
         fail(nullptr, F3D_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -232,6 +237,7 @@ void f3d_ctx_destroy(f3d_ctx* ctx) {
     if (ctx->table) (void)hipFree(ctx->table);
     if (ctx->filter_dev) (void)hipFree(ctx->filter_dev);
     if (ctx->count_dev) (void)hipFree(ctx->count_dev);
+    if (ctx->codebook) (void)hipFree(ctx->codebook);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -246,7 +252,7 @@ int f3d_ctx_synchronize(f3d_ctx* ctx) {
 
 void* f3d_ctx_stream(f3d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-static size_t fuse_todo_bytes(int64_t n) { return 16 + (size_t)n * 4; }
+static size_t fuse_todo_bytes(int64_t n) { return 16 + (size_t)n * 8; }     // 4 counters + two index lists (fast -> mid -> exact)
 
 int f3d_ctx_reserve(f3d_ctx* ctx, int64_t n, int nviews, int h, int w) {
     int rc = enter(ctx); if (rc) return rc;
@@ -332,6 +338,7 @@ int f3d_views_build(const double K[9], double w, double h, const double* q, cons
         // float64 refinement: FMA value and exact value are both within ~12 eps64 * (|p|_1 + |pp|_1) of the real number
         vw->cull_rel64 = 64.0 * 2.220446049250313e-16 * nmax;
         vw->cull_abs64 = 64.0 * 2.220446049250313e-16 * l1max + 1e-300;
+        vw->img_w = (float)w; vw->img_h = (float)h;
         vw->cull_rel32 = (float)(eps32 * nmax * 1.0000002);
         vw->cull_abs32 = (float)(eps32 * l1max * 1.0000002 + 1e-30);
         // fast projection operator M = K * Rot(qinv), Rot = the matrix of x -> q x q* for the un-normalised q
@@ -347,6 +354,7 @@ int f3d_views_build(const double K[9], double w, double h, const double* q, cons
                     long double acc = 0;
                     for (int k = 0; k < 3; ++k) acc += (long double)K[3 * r + k] * R[3 * k + c];
                     vw->M[3 * r + c] = (double)acc;
+                    vw->M32[3 * r + c] = (float)vw->M[3 * r + c];
                     l1 += fabsl((long double)K[3 * r + c]);
                 }
                 vw->mnorm[r] = (double)(l1 * q2 * 1.000000001L);
@@ -532,33 +540,48 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
         perm = (const int32_t*)sperm; gather = true;                                            // the kernel reads xyz[perm[i]]
     }
     const uint8_t* cmasks = nullptr;                                                            // coded, tiled copy for the fast kernel
-    if (nviews > 0 && nclasses <= F3D_CODE_MAX_NCLASSES) {
+    // the accelerated kernels address the coded masks with 32-bit offsets; beyond 4 GiB of them the exact kernel labels every point
+    if (nviews > 0 && nclasses <= F3D_CODE_MAX_NCLASSES && f3d_coded_masks_bytes(nviews, h, w) < ((size_t)1 << 32)) {
         void* tm;                                                                               // grows on first use only
         if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &tm))) return rc;
-        F3D_HIP(ctx, f3d_launch_code_masks(masks, (uint8_t*)tm, nviews, h, w, nclasses, s));
+        F3D_HIP(ctx, f3d_launch_code_masks(masks, (uint8_t*)tm, nviews, h, w, nclasses, fa, votes_u16 != nullptr, ctx->codebook, s));
         cmasks = (const uint8_t*)tm;
     }
     void* todo;                                                                                 // grows on first use only
     if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,
-                                 ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), s));
+                                 ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), ctx->codebook, s));
     return F3D_OK;
 }
 
-int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views, int nviews,
+int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views, int nviews, int w, int h,
                              uint64_t stats[4]) {
     int rc = enter(ctx); if (rc) return rc;
-    if (n < 0 || nviews < 0 || !stats || (n > 0 && !xyz) || (nviews > 0 && !views))
+    if (n < 0 || n > 0x7fffffffLL || nviews < 0 || w <= 0 || h <= 0 || !stats || (n > 0 && !xyz) || (nviews > 0 && !views))
         return fail(ctx, F3D_ERR_INVALID, "fastpath_audit: bad arguments");
-    void *dxyz, *dviews, *dstats;
+    void *dxyz, *dsorted, *dperm, *dviews, *dstats, *scratch;
     if ((rc = ensure(ctx, SLOT_XYZ, xyz_bytes(dtype, n), &dxyz))) return rc;
+    if ((rc = ensure(ctx, SLOT_OUT0, xyz_bytes(dtype, n), &dsorted))) return rc;
+    if ((rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &dperm))) return rc;
+    if ((rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &scratch))) return rc;
     if ((rc = ensure(ctx, SLOT_VIEWS, sizeof(f3d_view) * (size_t)nviews, &dviews))) return rc;
     if ((rc = ensure(ctx, SLOT_AUX0, 64, &dstats))) return rc;
     hipStream_t s = ctx->stream;
     if (n) F3D_HIP(ctx, hipMemcpyAsync(dxyz, xyz, xyz_bytes(dtype, n), hipMemcpyHostToDevice, s));
     if (nviews) F3D_HIP(ctx, hipMemcpyAsync(dviews, views, sizeof(f3d_view) * (size_t)nviews, hipMemcpyHostToDevice, s));
-    F3D_HIP(ctx, f3d_launch_fastpath_audit(dxyz, dtype, n, (const f3d_view*)dviews, nviews, (unsigned long long*)dstats, s));
+    // waves of 64 consecutive points must be spatial neighbours, as in the fused call: audit the cell-sorted copy
+    if (n) F3D_HIP(ctx, f3d_launch_cell_sort(dxyz, dtype, n, dsorted, (int32_t*)dperm, scratch, s));
+    F3D_HIP(ctx, f3d_launch_fastpath_audit(dsorted, dtype, n, (const f3d_view*)dviews, nviews, w, h, (unsigned long long*)dstats, s));
     F3D_HIP(ctx, hipMemcpyAsync(stats, dstats, 32, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+int f3d_debug_fuse_deferred(f3d_ctx* ctx, void* stream, uint32_t counts[2]) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (!counts || !ctx->slot[SLOT_TODO]) return fail(ctx, F3D_ERR_INVALID, "fuse_deferred: no fused call has run in this context");
+    hipStream_t s = pick(ctx, stream);
+    F3D_HIP(ctx, hipMemcpyAsync(counts, ctx->slot[SLOT_TODO], 8, hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
     return F3D_OK;
 }

@@ -1,0 +1,1226 @@
+// The fused multi-view path of libf3d_hip.so for gfx950 (MI355X, CDNA4; wave = 64 lanes):
+//   project -> sample -> vote -> segment   (fusion.py:254-266 + voting.py:94-137 composed per point)
+//
+//   k_mask_presence / k_code_lut / k_code_masks : the masks are rewritten once per call into 8x8-pixel tiles of vote-BIN
+//       CODES.  Only labels that occur in the masks (or, with filter_classes, only the filter labels) get a bin, so a
+//       thread's vote histogram is a handful of LDS dwords instead of 34.
+//   k_fuse        : the fast kernel.  One thread owns one point; all per-view arithmetic is FLOAT32: one lane per view
+//       projects the CENTRE of the wave's bounding box in float64, every lane adds the float32 offset term of its own
+//       point (|p - c| is a few centimetres after the cell sort, so float32 carries the pixel to ~1e-5 px) and accepts
+//       the pixel only when it is farther than a rigorous bound from a pixel border.  A point for which any decision
+//       cannot be proven is appended to a list and recomputed entirely by
+//   k_fuse_exact  : the reference's arithmetic and nothing else (exact 5-plane test, un-normalised quaternion sandwich,
+//       K @ c, IEEE divisions), launched right behind.
+// Results are exactly those of the reference arithmetic (oracle order).  No MFMA: nothing here is a dense contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "f3d.h"
+#include "f3d_math.h"
+#include "f3d_kernels.h"
+
+#pragma clang fp contract(off)
+
+#define F3D_BLOCK 256
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ f3d_p3 load_point(const T* __restrict__ xyz, int64_t i) {
+    const T* p = xyz + 3 * i;
+    f3d_p3 r;
+    r.x = (double)p[0]; r.y = (double)p[1]; r.z = (double)p[2];
+    return r;
+}
+
+enum { MODE_HIST8 = 0, MODE_HIST16 = 1 };
+
+// k-th entry of filter_classes: short lists travel in the kernarg, long ones in device memory
+__device__ __forceinline__ int filter_at(const f3d_filter_args& flt, int k) {
+    return (flt.nfilter <= 8) ? flt.cls[k & 7] : flt.cls_dev[k];
+}
+
+template <int MODE>
+struct hist_traits;
+template <> struct hist_traits<MODE_HIST8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
+template <> struct hist_traits<MODE_HIST16> { static constexpr int per_word = 2, shift = 1, bits = 16; static constexpr uint32_t mask = 0xFFFFu; };
+
+#ifndef F3D_CHUNK
+#define F3D_CHUNK 2                          // whole-wave views projected per gather batch
+#endif
+#define F3D_CULL_ROW 25                       // floats per view in the LDS cull table (24 used, odd stride = no bank conflicts)
+#define F3D_FAST_EPS 1.1368683772161603e-13   // 2^-43
+#define F3D_U24 5.9604644775390625e-08        // 2^-24
+
+// float32 cull planes of one view, copied by value (wave-uniform -> scalar loads -> SGPRs)
+struct cull_consts { float n[F3D_NPLANES][3]; float off[F3D_NPLANES]; float rel, abs; };
+__device__ __forceinline__ cull_consts load_cull(const f3d_view& vw) {
+    cull_consts cc;
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        cc.n[m][0] = vw.cull_n32[m][0]; cc.n[m][1] = vw.cull_n32[m][1]; cc.n[m][2] = vw.cull_n32[m][2]; cc.off[m] = vw.cull_off32[m];
+    }
+    cc.rel = vw.cull_rel32; cc.abs = vw.cull_abs32;
+    return cc;
+}
+// pin(): the copies exist in SGPRs at this point of the program.  Without it the compiler sinks each scalar load next to
+// its first use and the scalar-memory latency is paid once per use; with all loads of an iteration requested first and
+// pinned together it is paid once.
+__device__ __forceinline__ void pin(cull_consts& cc) {
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        asm volatile("" : "+s"(cc.n[m][0])); asm volatile("" : "+s"(cc.n[m][1])); asm volatile("" : "+s"(cc.n[m][2])); asm volatile("" : "+s"(cc.off[m]));
+    }
+    asm volatile("" : "+s"(cc.rel)); asm volatile("" : "+s"(cc.abs));
+}
+
+// per-point float32 cull against one view (SGPR-resident record): maybe = not surely outside, sure = surely inside
+__device__ __forceinline__ void cull_point32(const cull_consts& vw, float px, float py, float pz, float ps, bool small,
+                                             bool& maybe, bool& sure) {
+    const float marg = __builtin_fmaf(vw.rel, ps, vw.abs);
+    bool mb = true, sr = true;
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        const float a = __builtin_fmaf(vw.n[m][0], px,
+                        __builtin_fmaf(vw.n[m][1], py,
+                        __builtin_fmaf(vw.n[m][2], pz, -vw.off[m])));
+        mb = mb & (a > -marg);
+        sr = sr & (a > marg);
+    }
+    maybe = mb | !small;                      // huge / non-finite coordinates: only the exact test may decide
+    sure = sr & small;
+}
+
+// byte offset of pixel (iu, iv) inside one view's mask: row-major as the caller hands it over (the exact kernel), or in
+// the 8x8-pixel tiled copy (one 64-B line per tile) made by k_code_masks -- neighbouring points of a wave then share
+// cache lines in BOTH directions
+template <bool TILED>
+__device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W) {          // TILED: W = tiles per row of the coded plane (border included)
+    if (TILED) return (((unsigned)((iv + 8) >> 3) * (unsigned)W + (unsigned)((iu + 8) >> 3)) << 6) | ((unsigned)(iv & 7) << 3) | (unsigned)(iu & 7);
+    return (unsigned)(iv * W + iu);
+}
+
+// ------------------------------------------------------------------------------------------
+// Vote-bin codes.  Code 0 = "no sample" (k_code_masks ends every view with 64 such bytes, and a lane without a pixel
+// gathers from there instead of carrying a validity flag through the vote), code 1 = a label the reference would
+// reject (> nclasses, IndexError at voting.py:98), then
+//   presence book (no filter, or votes requested): one code per label that occurs in the masks, the SMALLEST label
+//       getting the LARGEST code, so that the maximum of (count << 8 | code) is count desc, label asc = np.argmax's
+//       first-maximum rule;
+//   filter book: code 2 = any other valid label (it only counts towards the total, voting.py:120), codes 3.. = the
+//       distinct entries of filter_classes.
+// The book is built on the device (k_mask_presence + k_code_lut), so no host round trip decides the histogram size:
+// the launcher enqueues a SMALL-histogram and a FULL-histogram instance of k_fuse and each returns at once unless the
+// book's size is in its range.
+// ------------------------------------------------------------------------------------------
+#define F3D_CODE_NONE 0u
+#define F3D_CODE_BAD 1u
+#define F3D_CODE_OTHER 2u
+#define F3D_BIN32_MAX_CODES 12               // alphabets up to this many codes vote into dword bins (12 KiB of LDS per 256 points: 4 blocks per CU)
+
+// One view of the coded masks: (ceil(H/8) + 2) x (ceil(W/8) + 2) tiles of 8x8 pixels (64 B each): the image plus a one-tile border of
+// "no sample" all around, so that pixel (-1, -1) .. (W, H) are addressable -- tile (0, 0) of view 0, at offset 0, is such a border tile
+// and serves as the address a lane without a pixel gathers from.
+__host__ __device__ inline int f3d_coded_pitch(int W) { return ((W + 7) >> 3) + 2; }
+__host__ __device__ inline size_t f3d_coded_plane(int H, int W) { return (size_t)(((H + 7) >> 3) + 2) * (size_t)f3d_coded_pitch(W) * 64; }
+
+// which labels occur in the masks.  A thread keeps a 256-bit set in four 64-bit registers; masks are piecewise constant,
+// so an 8-byte word whose bytes all equal the previous label costs two instructions.
+template <bool VEC>
+__global__ __launch_bounds__(F3D_BLOCK) void k_mask_presence(const uint8_t* __restrict__ src, int64_t nbytes, f3d_codebook* __restrict__ cb) {
+    unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    auto mark = [&](unsigned l) {
+        const unsigned long long bit = 1ull << (l & 63u);
+        const unsigned q = l >> 6;
+        m0 |= q == 0u ? bit : 0ull; m1 |= q == 1u ? bit : 0ull; m2 |= q == 2u ? bit : 0ull; m3 |= q == 3u ? bit : 0ull;
+    };
+    if (VEC) {
+        const int64_t nw = nbytes >> 3;
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(src);
+        uint64_t last = ~0ull;                                     // the previous word when all of its bytes were equal
+        for (int64_t k = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; k < nw; k += (int64_t)gridDim.x * F3D_BLOCK) {
+            const uint64_t x = w[k];
+            if (x == last) continue;
+            if (x == (x & 0xFFull) * 0x0101010101010101ull) { mark((unsigned)(x & 0xFFull)); last = x; continue; }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mark((unsigned)(x >> (8 * c)) & 0xFFu);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (nbytes & 7)) mark(src[(nw << 3) + threadIdx.x]);
+    } else {
+        for (int64_t k = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; k < nbytes; k += (int64_t)gridDim.x * F3D_BLOCK) mark(src[k]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        m0 |= __shfl_xor(m0, off, 64); m1 |= __shfl_xor(m1, off, 64); m2 |= __shfl_xor(m2, off, 64); m3 |= __shfl_xor(m3, off, 64);
+    }
+    // block-level OR in LDS, then one thread per dword adds only the bits the global set still lacks: thousands of waves
+    // hammering the same 8 dwords with atomics cost 0.38 ms; masks share their alphabet, so almost every block finds its bits set
+    __shared__ unsigned blk[8];
+    if (threadIdx.x < 8) blk[threadIdx.x] = 0u;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long m[4] = {m0, m1, m2, m3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if ((unsigned)m[q]) atomicOr(&blk[2 * q], (unsigned)m[q]);
+            if ((unsigned)(m[q] >> 32)) atomicOr(&blk[2 * q + 1], (unsigned)(m[q] >> 32));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const unsigned want = blk[threadIdx.x];
+        const unsigned have = __hip_atomic_load(&cb->presence[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (want & ~have) atomicOr(&cb->presence[threadIdx.x], want);
+    }
+}
+
+// one block of 256 threads: thread l decides the code of label l.  book: 0 = every label 0..nclasses has a bin (no
+// presence pass ran), 1 = presence book, 2 = filter book.
+__global__ __launch_bounds__(F3D_BLOCK) void k_code_lut(f3d_codebook* __restrict__ cb, int nclasses, int book, f3d_filter_args flt) {
+    __shared__ unsigned pres[8];
+    __shared__ int first_of[256];                                  // filter book: position of label l's first occurrence, -1 = not listed
+    const unsigned l = threadIdx.x;
+    if (l < 8) pres[l] = book == 1 ? cb->presence[l] : 0xFFFFFFFFu;
+    first_of[l] = -1;
+    cb->inv[l] = 0;
+    __syncthreads();
+    if (book == 2) {
+        if (l == 0)
+            for (int k = flt.nfilter - 1; k >= 0; --k) { const int f = filter_at(flt, k); if (f >= 0 && f < 256) first_of[f] = k; }
+        __syncthreads();
+        const bool listed = first_of[l] >= 0 && (int)l <= nclasses;
+        int rank = 0;                                              // distinct listed labels below l
+        for (unsigned j = 0; j < l; ++j) rank += (first_of[j] >= 0 && (int)j <= nclasses) ? 1 : 0;
+        int distinct = 0;
+        for (unsigned j = 0; j < 256; ++j) distinct += (first_of[j] >= 0 && (int)j <= nclasses) ? 1 : 0;
+        const unsigned code = (int)l > nclasses ? F3D_CODE_BAD : (listed ? 3u + (unsigned)rank : F3D_CODE_OTHER);
+        cb->lut[l] = (uint8_t)code;
+        if (listed) cb->inv[code] = (uint8_t)l;
+        if (l == 0) { cb->ncodes = 3 + distinct; cb->words = (3 + distinct + 3) >> 2; cb->book = 2; }
+        return;
+    }
+    const bool pv = (int)l <= nclasses && ((pres[l >> 5] >> (l & 31u)) & 1u);     // label l is valid and present
+    __shared__ unsigned long long wb[4];
+    const unsigned long long bal = __ballot(pv);
+    if ((l & 63u) == 0u) wb[l >> 6] = bal;
+    __syncthreads();
+    int K = 0, below = __popcll(bal & ((1ull << (l & 63u)) - 1ull));
+    for (unsigned w = 0; w < 4; ++w) { const int c = __popcll(wb[w]); K += c; below += (w < (l >> 6)) ? c : 0; }
+    unsigned code;
+    if ((int)l > nclasses) code = F3D_CODE_BAD;                    // only meaningful when such a byte really occurs
+    else if (pv) code = (unsigned)(K + 1 - below);                 // smallest present label -> K + 1, largest -> 2
+    else code = F3D_CODE_NONE;                                     // never gathered; its vote row reads the always-zero bin 0
+    cb->lut[l] = (uint8_t)code;
+    if (code >= 2u) cb->inv[code] = (uint8_t)l;
+    if (l == 0) { cb->ncodes = K + 2; cb->words = (K + 2 + 3) >> 2; cb->book = book; }
+}
+
+// [V,H,W] row-major labels -> [V][ceil(H/8) + 2][ceil(W/8) + 2][8][8] bin codes (border tiles = "no sample"); one thread moves one
+// tile row (8 bytes), a wave writes 512 contiguous bytes.  VEC: W % 8 == 0 and src 8-B aligned (one 8-B load per thread).
+template <bool VEC>
+__global__ __launch_bounds__(F3D_BLOCK) void k_code_masks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int V, int H, int W,
+                                                           const f3d_codebook* __restrict__ cb) {
+    __shared__ uint32_t lut_w[64];
+    if (threadIdx.x < 64) lut_w[threadIdx.x] = reinterpret_cast<const uint32_t*>(cb->lut)[threadIdx.x];
+    __syncthreads();
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lut_w);
+    const int tw = f3d_coded_pitch(W), th = ((H + 7) >> 3) + 2;    // border included
+    const int64_t per_view = (int64_t)th * tw * 8;                 // 8-byte pieces per view
+    const int64_t total = per_view * V;
+    const size_t tplane = f3d_coded_plane(H, W);
+    for (int64_t k = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; k < total; k += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t v = k / per_view; const int64_t r = k - v * per_view;      // r indexes (tile, row-in-tile) of the destination
+        uint64_t out = 0;                                                         // border and padding: F3D_CODE_NONE
+        const int tile = (int)(r >> 3), ry = (int)(r & 7);
+        const int ty = tile / tw, tx = tile - ty * tw;
+        const int y = (ty - 1) * 8 + ry, x0 = (tx - 1) * 8;
+        if (y >= 0 && y < H && x0 >= 0 && x0 < W) {
+            const uint8_t* row = src + (size_t)v * H * W + (size_t)y * W + x0;
+            if (VEC) {
+                const uint64_t x = *reinterpret_cast<const uint64_t*>(row);
+                if (x == (x & 0xFFull) * 0x0101010101010101ull) out = (uint64_t)lut[x & 0xFFull] * 0x0101010101010101ull;
+                else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) out |= (uint64_t)lut[(x >> (8 * c)) & 0xFFull] << (8 * c);
+                }
+            } else {
+                for (int c = 0; c < 8; ++c) if (x0 + c < W) out |= (uint64_t)lut[row[c]] << (8 * c);
+            }
+        }
+        *reinterpret_cast<uint64_t*>(dst + (size_t)v * tplane + (size_t)r * 8) = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Centre + offset projection.  For a wave whose 64 points lie in the box c +- E (float32 centre, half extents) and a
+// view with operator M = K Rot(qinv) and translation t, the view's lane projects the CENTRE in float64:
+//     h = M (c - t),   z_c = h_2,   u_c = h_0 / h_2 = U + uf   (U integer, uf in [0, 1)),   likewise v_c = V + vf.
+// With d = p - c the pixel coordinate of a point of the wave is, exactly,
+//     u(p) - U = uf + (sum_j a0_j d_j) / (1 + sum_j b_j d_j),     a0_j = (M_0j - u_c M_2j) / z_c,   b_j = M_2j / z_c
+// (and a1_j = (M_1j - v_c M_2j) / z_c for v).  The lane rounds a0, a1, b, uf, vf to float32 ONCE per (wave, view); every
+// lane then evaluates  w = uf + (a0 . d) * rcp(1 + b . d)  in float32 -- |d| is a few centimetres after the cell sort, so
+// w is a small number carried to ~1e-5 px -- and the pixel U + floor(w) is accepted when w is farther than the bound
+// below from an integer.  The 14 floats of a row reach the other lanes through v_readlane when the view's turn comes:
+// the view loop touches neither scalar memory nor LDS for its constants.
+// Error budget, u = 2^-24, per coordinate, with X = sum_j |a_j| E_j (>= |a . d| over the box), Q = sum_j |b_j| E_j < 1/2,
+// smax = 1 / (1 - Q) (>= rcp(1 + b . d)), D = X smax (>= |w - uf|):
+//   a . d : a and (float)(p - c) carry u each, the 3-FMA chain 3 more            -> 5.01 u X
+//   1 + q : the same for b . d (5.01 u Q), the add (u (1 + Q)), v_rcp_f32 (1 ulp)  -> relative u (1 + (1 + 6.01 Q) smax)
+//   w     : the final FMA (u (D + 8)) and (float)uf (4 u: uf is taken from a tile border, 0 <= uf < 8)
+//   B32 = 1.5 u (D (7.01 + (1 + 6.01 Q) smax) + 12.5)                              (1.5: safety factor)
+// On top of it twice the float64 bound 2^-43 (|d|_1 |r| (mnorm_k + |u| mnorm_2) + |u|) of "M (p - t) in FMAs against the
+// canonical operation order" (both are within ~50 eps of the real number; 2^-43 is a > 10x margin), once for the centre
+// the row is derived from and once for the point, evaluated over the box.
+// A view whose box comes close to the camera plane (Q >= 1/2), is huge, or projects absurdly far gets no row (ok = false):
+// its visible points go to the next tier.
+// ------------------------------------------------------------------------------------------
+// uf, vf: u_c - U8, v_c - V8 in [0, 8) with U8 = floor(u_c) rounded down to a multiple of 8 (a tile border), so that the integer part of
+// a pixel only enters the tile arithmetic through obase = the offset of pixel (U8, V8) inside the view's coded plane; U8, V8 themselves are
+// only needed for the image-range test of the mixed views.  hb: half width of the accepted fraction band.
+struct centre_row { float b0, b1, b2, a00, a01, a02, a10, a11, a12, uf, vf, hb; unsigned obase; int U8, V8; };
+
+__device__ __forceinline__ double rcp_newton(double x) {            // 1/x to ~1 ulp without the IEEE division's register appetite
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+
+// vt: the view's first 15 doubles (M[9], t[3], mnorm[3] -- the head of f3d_view) with stride `vs` between them: straight from the
+// record (vs = 1) or from the block's LDS copy laid out [field][view] (vs = 64; lanes-over-views reads are then conflict-free
+// instead of 64 scattered cache lines per load)
+#define F3D_VHEAD 15
+#ifndef F3D_VT
+#define F3D_VT                           // (volatile was tried to stop the hoisting of these tile-invariant reads: more spills, not fewer)
+#endif
+__device__ __forceinline__ bool centre_precompute(const F3D_VT double* vt, int vs, float c0, float c1, float c2, float e0, float e1, float e2,
+                                                   float umaxf, int pitch, centre_row& row) {
+    const double M0 = vt[0], M1 = vt[vs], M2 = vt[2 * vs], M3 = vt[3 * vs], M4 = vt[4 * vs], M5 = vt[5 * vs], M6 = vt[6 * vs], M7 = vt[7 * vs],
+                 M8 = vt[8 * vs];
+    const double d0 = (double)c0 - vt[9 * vs], d1 = (double)c1 - vt[10 * vs], d2 = (double)c2 - vt[11 * vs];
+    const double h0 = __builtin_fma(M0, d0, __builtin_fma(M1, d1, M2 * d2));
+    const double h1 = __builtin_fma(M3, d0, __builtin_fma(M4, d1, M5 * d2));
+    const double h2 = __builtin_fma(M6, d0, __builtin_fma(M7, d1, M8 * d2));
+    const double rc = rcp_newton(h2);
+    const double uc = h0 * rc, vc = h1 * rc;
+    const double U = floor(uc), V = floor(vc);
+    row.b0 = (float)(M6 * rc); row.b1 = (float)(M7 * rc); row.b2 = (float)(M8 * rc);
+    row.a00 = (float)(__builtin_fma(-uc, M6, M0) * rc); row.a01 = (float)(__builtin_fma(-uc, M7, M1) * rc); row.a02 = (float)(__builtin_fma(-uc, M8, M2) * rc);
+    row.a10 = (float)(__builtin_fma(-vc, M6, M3) * rc); row.a11 = (float)(__builtin_fma(-vc, M7, M4) * rc); row.a12 = (float)(__builtin_fma(-vc, M8, M5) * rc);
+    const double U8 = floor(uc * 0.125) * 8.0, V8 = floor(vc * 0.125) * 8.0;
+    row.uf = (float)(uc - U8); row.vf = (float)(vc - V8);
+    row.U8 = (int)U8; row.V8 = (int)V8;                                            // |U|, |V| < 32768 is required below
+    row.obase = (unsigned)(((row.V8 + 8) >> 3) * pitch + ((row.U8 + 8) >> 3)) << 6;
+    // the bounds in float32, every step rounded up by the factor k (they only have to be upper bounds); the float32 row entries
+    // are within 2^-24 of the real a, b, which k covers as well
+    const float k = 1.00001f;
+    const float E0 = (e0 + 1.2e-7f * (fabsf(c0) + e0)) * k, E1 = (e1 + 1.2e-7f * (fabsf(c1) + e1)) * k,
+                E2 = (e2 + 1.2e-7f * (fabsf(c2) + e2)) * k;                       // the box is of float32-rounded coordinates
+    const float X0 = (fabsf(row.a00) * E0 + fabsf(row.a01) * E1 + fabsf(row.a02) * E2) * k;
+    const float X1 = (fabsf(row.a10) * E0 + fabsf(row.a11) * E1 + fabsf(row.a12) * E2) * k;
+    const float Q = (fabsf(row.b0) * E0 + fabsf(row.b1) * E1 + fabsf(row.b2) * E2) * k;
+    const float smax = k * k / (1.0f - Q);                                         // float32 division: 2.5 ulp, covered by k * k
+    const float D = fmaxf(X0, X1) * smax * k;
+    const float B32 = 1.5f * (float)F3D_U24 * (D * (7.01f + (1.0f + 6.01f * Q) * smax) + 12.5f) * k;   // |w| <= D + 8, (float)uf carries 4 u
+    const float arc = fabsf((float)rc) * k;
+    const float d1max = ((fabsf((float)d0) + fabsf((float)d1)) + fabsf((float)d2) + ((E0 + E1) + E2)) * k;
+    const float c1b = (2.0f * umaxf * (float)vt[14 * vs] + fmaxf((float)vt[12 * vs], (float)vt[13 * vs])) * k;
+    const float b64 = (float)F3D_FAST_EPS * (d1max * arc * smax * c1b + 2.0f * umaxf) * k;   // |r| <= |rc| smax over the box
+    const float hb = (0.5f - (B32 + 2.0f * b64) * k - 4.0f * (float)F3D_U24) * 0.99999f;
+    row.hb = hb;
+    // every comparison is false for NaN: a degenerate box or view simply is not taken this way
+    return (h2 > 0.0) && (Q < 0.5f) && (B32 < 1.0e-3f) && (hb > 0.25f) && (fabs(U) < 32768.0) && (fabs(V) < 32768.0) &&
+           (fabs(uc) <= 2.0 * (double)umaxf) && (fabs(vc) <= 2.0 * (double)umaxf);
+}
+
+// the row of view `bit` of the current 64-view group, broadcast out of the lane that computed it (v_readlane -> SGPRs)
+__device__ __forceinline__ centre_row read_row(const centre_row& mine, int bit) {
+    centre_row r;
+#define F3D_RL(f) r.f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.f), bit))
+    F3D_RL(b0); F3D_RL(b1); F3D_RL(b2); F3D_RL(a00); F3D_RL(a01); F3D_RL(a02); F3D_RL(a10); F3D_RL(a11); F3D_RL(a12);
+    F3D_RL(uf); F3D_RL(vf); F3D_RL(hb);
+#undef F3D_RL
+    r.obase = (unsigned)__builtin_amdgcn_readlane((int)mine.obase, bit);
+    r.U8 = 0; r.V8 = 0;                                            // (read separately where the range test needs them)
+    return r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float x) { return (f32x2){x, x}; }
+#define F3D_FMA2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+
+// The two points of a lane against one row, in packed float32 (v_pk_fma_f32: one issue slot for both points).  fi0, fi1 = the pixel
+// relative to the row's tile border (U8, V8) -- small integers, possibly negative; safe = "this pixel is proven".
+__device__ __forceinline__ void project_offset2(const centre_row& r, f32x2 DX, f32x2 DY, f32x2 DZ, int fi0[2], int fi1[2], bool safe[2]) {
+    const f32x2 q = F3D_FMA2(splat2(r.b0), DX, F3D_FMA2(splat2(r.b1), DY, F3D_FMA2(splat2(r.b2), DZ, splat2(1.0f))));
+    const f32x2 x0 = F3D_FMA2(splat2(r.a00), DX, F3D_FMA2(splat2(r.a01), DY, splat2(r.a02) * DZ));
+    const f32x2 x1 = F3D_FMA2(splat2(r.a10), DX, F3D_FMA2(splat2(r.a11), DY, splat2(r.a12) * DZ));
+    const f32x2 sr = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+    const f32x2 w0 = F3D_FMA2(x0, sr, splat2(r.uf)), w1 = F3D_FMA2(x1, sr, splat2(r.vf));
+    const f32x2 f0 = {__builtin_floorf(w0.x), __builtin_floorf(w0.y)}, f1 = {__builtin_floorf(w1.x), __builtin_floorf(w1.y)};
+    const f32x2 g0 = (w0 - f0) - splat2(0.5f), g1 = (w1 - f1) - splat2(0.5f);
+    safe[0] = __builtin_fmaxf(__builtin_fabsf(g0.x), __builtin_fabsf(g1.x)) < r.hb;   // NaN -> false (fmax drops one NaN, not two:
+    safe[1] = __builtin_fmaxf(__builtin_fabsf(g0.y), __builtin_fabsf(g1.y)) < r.hb;   //  a NaN pixel has both coordinates NaN -- q is shared)
+    fi0[0] = (int)f0.x; fi0[1] = (int)f0.y; fi1[0] = (int)f1.x; fi1[1] = (int)f1.y;
+}
+
+// offset of pixel (U8 + fi0, V8 + fi1) in the view's coded plane = obase + this; c_row = 64 * pitch - 64.
+// (fi + 56 (fi >> 3) = (fi & 7) + 64 (fi >> 3), and 8 fi + (64 pitch - 64)(fi >> 3) = 8 (fi & 7) + 64 pitch (fi >> 3); arithmetic shifts.)
+__device__ __forceinline__ unsigned rel_offset(int fi0, int fi1, int c_row) {
+    return (unsigned)((fi0 + 56 * (fi0 >> 3)) + ((fi1 << 3) + c_row * (fi1 >> 3)));
+}
+
+// single point (audit kernel): absolute pixel and "proven"
+__device__ __forceinline__ bool project_offset(const centre_row& r, float dx, float dy, float dz, int& iu, int& iv) {
+    int fi0[2], fi1[2]; bool safe[2];
+    project_offset2(r, splat2(dx), splat2(dy), splat2(dz), fi0, fi1, safe);
+    iu = fi0[0] + r.U8; iv = fi1[0] + r.V8;
+    return safe[0];
+}
+
+__device__ __forceinline__ void project_exact(const f3d_view& vw, f3d_p3 p, double& fu, double& fv) {
+    const f3d_p3 h = f3d_project_h(vw.K, vw.qinv, vw.t, p);
+    fu = floor(h.x / h.z); fv = floor(h.y / h.z);
+}
+
+// ---- vote state of the exact kernel (k_fuse_exact): bins indexed by the label itself
+template <int MODE>
+struct vote_state {
+    int total = 0;
+    unsigned best = 0;                   // (count << 16) | (0xFFFF - label): the maximum is the highest count, then the lowest label
+    bool bad = false;
+};
+
+// branch-free vote: lanes without a sample vote into a spare bin (index ncols) that nothing reads
+template <int MODE>
+__device__ __forceinline__ void vote_add(vote_state<MODE>& st, uint32_t* hist, int tid, const f3d_filter_args& flt, int nclasses,
+                                         bool valid, int label) {
+    using HT = hist_traits<MODE>;
+    st.bad = st.bad | (valid & (label > nclasses));                              // IndexError in the reference (flagged per tile)
+    valid = valid & (label <= nclasses);
+    st.total += valid ? 1 : 0;
+    const unsigned l = valid ? (unsigned)label : (unsigned)nclasses + 1u;
+    const unsigned sh = (l & (HT::per_word - 1)) * HT::bits;
+    const uint32_t old = atomicAdd(&hist[(l >> HT::shift) * F3D_BLOCK + tid], 1u << sh);
+    const unsigned c = ((old >> sh) & HT::mask) + 1u;
+    const unsigned key = valid ? ((c << 16) | (0xFFFFu - l)) : 0u;
+    st.best = st.best > key ? st.best : key;
+}
+
+// VotingSegmentation.segment (voting.py:120-135) for one point given the winner, then the store
+template <typename FilterAt>
+__device__ __forceinline__ int64_t segment_point(int win_c, int win_i, int total, int nfilter, FilterAt fat, int nclasses, double threshold) {
+    int64_t cls;
+    if (total == 0) cls = nclasses;                                                // :126
+    else {
+        cls = win_i;
+        if ((double)win_c / (double)total < threshold) cls = nclasses;             // :128-130
+        if (win_c == 0) cls = nclasses;                                            // :131
+    }
+    if (nfilter > 0) {                                                             // sequential remap (Q3)
+        int64_t r = cls;
+        for (int k = 0; k < nfilter; ++k) if (r == k) r = fat(k);
+        cls = r;
+    }
+    return cls;
+}
+
+template <int MODE, bool WRITE_VOTES>
+__device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const uint32_t* hist, int tid, const f3d_filter_args& flt,
+                                             int nclasses, double threshold, bool store, int64_t orig,
+                                             int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out) {
+    using HT = hist_traits<MODE>;
+    const int ncols = nclasses + 1;
+    int win_c, win_i;
+    if (flt.nfilter > 0) {                                                       // votes[:, filter_classes]: first maximum wins
+        win_c = -1; win_i = 0;
+        for (int k = 0; k < flt.nfilter; ++k) {
+            const int l = filter_at(flt, k);
+            int c = 0;
+            if (l >= 0 && l < ncols) c = (int)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
+            if (c > win_c) { win_c = c; win_i = k; }
+        }
+    } else {
+        win_c = (int)(st.best >> 16); win_i = (int)(0xFFFFu - (st.best & 0xFFFFu));
+    }
+    const int64_t cls = segment_point(win_c, win_i, st.total, flt.nfilter, [&](int k) { return filter_at(flt, k); }, nclasses, threshold);
+    if (store) classes[orig] = cls;
+    if (WRITE_VOTES && store) {
+        for (int l = 0; l < ncols; ++l)
+            votes_out[(size_t)orig * ncols + l] =
+                (uint16_t)((hist[(l >> HT::shift) * F3D_BLOCK + tid] >> ((l & (HT::per_word - 1)) * HT::bits)) & HT::mask);
+    }
+}
+
+// ---- the fast kernel's vote: `b` is a bin code gathered from the coded masks; hcol = the point's histogram column (bins of
+// word w at hcol[w * F3D_BLOCK]).  No validity flag, no label range test, no returned value to wait for (ds_add_u32): "no
+// sample" lands in bin 0, which nothing reads; the plurality is found by one scan over the few bins at the end.
+// WRAP (more than 255 views): an 8-bit bin may wrap, so bin 0 must stay 0 and the votes are counted (see finish_coded).
+// dword bins (small alphabets): bin of code b at hcol[b * F3D_BLOCK]; the vote is an address computation and a ds_add_u32
+__device__ __forceinline__ void vote_bin32(uint32_t* hcol, unsigned b) { atomicAdd(&hcol[b * F3D_BLOCK], 1u); }
+
+// VotingSegmentation.segment (voting.py:120-135) for one point from dword bins, then the stores
+template <bool WRITE_VOTES>
+__device__ __forceinline__ void finish_bin32(const uint32_t* hcol, int ncodes, const uint8_t* lut, const uint8_t* inv, int nfilter,
+                                             const int* __restrict__ fcls, int nclasses, double threshold, bool store, int orig,
+                                             int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad) {
+    const int ncols = nclasses + 1;
+    const unsigned cbad = hcol[F3D_BLOCK];
+    bad = cbad != 0u;
+    unsigned best = 0, sum = cbad;
+    for (int c = 2; c < ncodes; ++c) {
+        const unsigned n = hcol[c * F3D_BLOCK];
+        const unsigned key = (n << 8) | (unsigned)c;                               // count desc, then code desc = label asc
+        sum += n;
+        best = best > key ? best : key;
+    }
+    int win_c, win_i;
+    if (nfilter > 0) {                                                             // votes[:, filter_classes]: first maximum wins
+        win_c = -1; win_i = 0;
+        for (int k = 0; k < nfilter; ++k) {
+            const int l = fcls[k];                                                 // wave-uniform: scalar load
+            int c = 0;
+            if (l >= 0 && l < ncols) { const unsigned b = lut[l]; c = b >= 2u ? (int)hcol[b * F3D_BLOCK] : 0; }
+            if (c > win_c) { win_c = c; win_i = k; }
+        }
+    } else {
+        win_c = (int)(best >> 8); win_i = (int)inv[best & 0xFFu];
+    }
+    const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold);
+    if (store) classes[orig] = cls;
+    if (WRITE_VOTES && store) {
+        for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? hcol[b * F3D_BLOCK] : 0u); }
+    }
+}
+
+template <bool WRAP>
+__device__ __forceinline__ void vote_coded(unsigned& nvalid, uint32_t* hcol, unsigned b) {
+    if (WRAP) {
+        const unsigned one = b < 1u ? b : 1u;                                      // 0 for F3D_CODE_NONE
+        nvalid += one;
+        atomicAdd(&hcol[(b >> 2) * F3D_BLOCK], one << ((b & 3u) * 8u));
+    } else {
+        atomicAdd(&hcol[(b >> 2) * F3D_BLOCK], 1u << ((b & 3u) * 8u));
+    }
+}
+
+__device__ __forceinline__ unsigned coded_count(const uint32_t* hcol, unsigned b) {
+    return (hcol[(b >> 2) * F3D_BLOCK] >> ((b & 3u) * 8u)) & 0xFFu;
+}
+
+// VotingSegmentation.segment (voting.py:120-135) for one point of the fast kernel, then the stores.  Returns false when the
+// 8-bit bins cannot be trusted (one of them wrapped: more than 255 agreeing views) -- the point then goes to the exact kernel.
+template <bool WRITE_VOTES, bool WRAP>
+__device__ __forceinline__ bool finish_coded(unsigned nvalid, const uint32_t* hcol, int words, const uint8_t* lut, const uint8_t* inv,
+                                             int nfilter, const int* __restrict__ fcls, int nclasses, double threshold, bool store,
+                                             int orig, int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad) {
+    const int ncols = nclasses + 1;
+    unsigned best = 0, sum = 0;
+    {
+        const unsigned x = hcol[0];                                                // codes 0 (no sample: ignored), 1 (rejected label), 2, 3
+        bad = ((x >> 8) & 0xFFu) != 0u;
+        const unsigned c2 = (x >> 16) & 0xFFu, c3 = x >> 24;
+        sum = ((x >> 8) & 0xFFu) + c2 + c3;
+        best = (c2 << 8) | 2u;
+        const unsigned k3 = (c3 << 8) | 3u;
+        best = best > k3 ? best : k3;
+    }
+    for (int w = 1; w < words; ++w) {
+        const unsigned x = hcol[w * F3D_BLOCK];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned c = (x >> (8 * j)) & 0xFFu;
+            const unsigned key = (c << 8) | (unsigned)(4 * w + j);
+            sum += c;
+            best = best > key ? best : key;
+        }
+    }
+    // a bin that wrapped (256 votes) drops 256 from its own field and adds at most 1 to its neighbour's: the sum of the fields
+    // then falls short of the number of votes cast.  Only possible with more than 255 views.
+    if (WRAP && sum != nvalid) return false;
+    int win_c, win_i;
+    if (nfilter > 0) {                                                             // votes[:, filter_classes]: first maximum wins
+        win_c = -1; win_i = 0;
+        for (int k = 0; k < nfilter; ++k) {
+            const int l = fcls[k];                                                 // wave-uniform: scalar load
+            int c = 0;
+            if (l >= 0 && l < ncols) { const unsigned b = lut[l]; c = b >= 2u ? (int)coded_count(hcol, b) : 0; }
+            if (c > win_c) { win_c = c; win_i = k; }
+        }
+    } else {
+        win_c = (int)(best >> 8); win_i = (int)inv[best & 0xFFu];
+    }
+    // total = the votes cast (every bin but "no sample"; a rejected label raises IndexError anyway)
+    const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold);
+    if (store) classes[orig] = cls;
+    if (WRITE_VOTES && store) {                                                    // presence book: an absent label reads bin 0 = 0
+        for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? coded_count(hcol, b) : 0u); }
+    }
+    return true;
+}
+
+// Wave-wide min / max of a float through DPP (no LDS traffic, no s_waitcnt): xor-1 and xor-2 inside quads, mirror the half
+// rows and the rows (every lane of a 16-lane row then holds the row's result), row_bcast15 / row_bcast31 carry it across the
+// rows into lane 63, which is read back as a scalar.  6 VALU + 1 v_readlane per value.  Inputs are never NaN (+-inf for
+// lanes without a point).  Must be called with all 64 lanes active.
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+    // written as one asm block: the compiler's own lowering of update_dpp + fminf spends 4 VALU per step (copy, v_mov_dpp,
+    // canonicalise, min); v_min/v_max take the DPP operand directly.  s_nop 1 = the 2 wait states a DPP read needs after
+    // a VALU write of the same register.
+#define F3D_DPP_CHAIN(op)                                                                  \
+    asm volatile("s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+                 "s_nop 1" : "+v"(v))
+    if (MAX) F3D_DPP_CHAIN("v_max_f32_dpp"); else F3D_DPP_CHAIN("v_min_f32_dpp");
+#undef F3D_DPP_CHAIN
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fuse: the fast kernel.  It contains NO exact arithmetic and no float64 in its view loop: a point for which any
+// accelerator cannot prove its decision (a plane within the rounding margin, a pixel within the bound of a pixel border, a
+// view without a usable centre row, huge or non-finite coordinates, a wrapped 8-bit bin) is not stored; its index is
+// appended to `todo` and the next tier recomputes that point entirely.
+//  * The kernel's time follows the NUMBER of vector instructions issued (measured: ~4.5 cycles per wave instruction whatever
+//    its width; replacing float64 by float32 at equal count changed nothing), so the view loop is written for few of them:
+//    a lane owns TWO points (a wave = 128 consecutive points of the cell-sorted cloud) and evaluates both with packed float32
+//    (v_pk_fma_f32: one issue slot for two points); the 13 wave-uniform numbers of a view arrive through v_readlane once for
+//    both; the integer part of the pixel is folded into a scalar tile offset (no per-lane "+ U"); a vote into dword bins is
+//    two instructions.
+//  (A) tile pre-cull, lanes-over-views: each wave reduces the bounding box of its points, lane j tests the box against the 5
+//      planes of view 64g+j (float32 planes staged in LDS): box behind a plane -> the wave skips the view (scalar bit-scan);
+//      box inside all planes -> no per-point cull and -- the frustum being the image's own pyramid -- no image-range test:
+//      the coded masks carry a one-tile "no sample" border for the last-bit cases.
+//  (B) per-point cull for the remaining "mixed" views in OFFSET form: the view's lane evaluates n . (c - plane point) once per
+//      wave, every lane adds n32 . (p - c) -- the float32 offset arithmetic adds only ~1e-7 m to the margin.
+//  (D) centre + offset projection (above) for every visible view.
+// Vote histograms live in LDS as [point][bin][thread] (conflict-free): BIN32 = one dword per code for alphabets of at most
+// F3D_BIN32_MAX_CODES codes, otherwise 8-bit bins packed 4 per dword.  The launcher enqueues one instance of each kind; an
+// instance returns at once unless the code book's size is in its range [cmin, cmax].
+// ------------------------------------------------------------------------------------------
+#ifndef F3D_FUSE_WAVES
+#define F3D_FUSE_WAVES 3                 // waves per SIMD the register allocation of k_fuse must allow (4 spills: measured slower)
+#endif
+template <typename T, bool WRITE_VOTES, bool BIN32, bool WRAP>
+__global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __restrict__ xyz, int64_t n,
+                                                     const f3d_view* __restrict__ views, int nviews,
+                                                     const uint8_t* __restrict__ cmasks, int H, int W,
+                                                     int nclasses, int nfilter, const int* __restrict__ fcls, double threshold,
+                                                     int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
+                                                     int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
+                                                     unsigned int* __restrict__ todo_count, int32_t* __restrict__ todo,
+                                                     const f3d_codebook* __restrict__ cb, int cmin, int cmax) {
+    const int ncodes = cb->ncodes;                                        // wave-uniform: scalar load
+    if (ncodes > cmax || ncodes < cmin) return;                           // the other instance's book
+    const int words = (ncodes + 3) >> 2;
+    const int hdw = BIN32 ? ncodes : words;                               // histogram dwords per point
+    extern __shared__ uint32_t lds_u32[];
+    float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes (+ image size) of one view group
+    uint32_t* lutw = lds_u32 + 64 * F3D_CULL_ROW;                         // lut[256] then inv[256] (bytes)
+    double* vtab = reinterpret_cast<double*>(lutw + 128);                 // [F3D_VHEAD][64]: M, t, mnorm of the group's views
+    uint32_t* hist = lutw + 128 + 2 * F3D_VHEAD * 64;                     // [2][hdw][F3D_BLOCK]
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
+    const uint8_t* inv = lut + 256;
+    const int tid = threadIdx.x, lane = threadIdx.x & 63;
+    constexpr int TILE = F3D_BLOCK * 2;
+    const int npts = (int)n;                                              // n < 2^31 - TILE (checked by the launcher): 32-bit indices
+    const int ntiles = (int)((n + TILE - 1) / TILE);
+    const unsigned plane = (unsigned)f3d_coded_plane(H, W);               // bytes per view of the coded masks (V * plane < 2^32: launcher)
+    const int pitch = f3d_coded_pitch(W);                                 // tiles per row, border included
+    const int c_row = 64 * pitch - 64;
+    const int ngroups = (nviews + 63) >> 6;
+    const float umaxf = (float)(W > H ? W : H), Wf = (float)W, Hf = (float)H;
+
+    if (tid < 128) lutw[tid] = reinterpret_cast<const uint32_t*>(cb->lut)[tid];   // lut and inv are adjacent in the book
+    auto stage_group = [&](int g) {                                       // whole block; caller brackets with barriers
+        const int nv = min(64, nviews - 64 * g);
+        for (int k = tid; k < nv * 24; k += F3D_BLOCK) {
+            const int vi = k / 24, f = k - vi * 24;
+            ctab[vi * F3D_CULL_ROW + f] = reinterpret_cast<const float*>(&views[64 * g + vi].cull_n32[0][0])[f];
+        }
+        for (int k = tid; k < nv * F3D_VHEAD; k += F3D_BLOCK) {
+            const int vi = k / F3D_VHEAD, f = k - vi * F3D_VHEAD;
+            vtab[f * 64 + vi] = reinterpret_cast<const double*>(&views[64 * g + vi])[f];
+        }
+    };
+    if (ngroups == 1) stage_group(0);
+    __syncthreads();
+
+    // XCD-aware tile mapping: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so XCD x walks the
+    // contiguous tile range [x*q, (x+1)*q): with a cell-sorted cloud that is one compact region of space, whose pixels
+    // in every mask stay resident in that XCD's 4 MiB L2.  Placement affects speed only, never results.
+    const int tiles_per_xcd = (ntiles + 7) / 8;
+    const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = gridDim.x >> 3;
+    uint32_t* const hcol0 = hist + tid;
+    uint32_t* const hcol1 = hist + hdw * F3D_BLOCK + tid;
+    for (int j = bx; j < tiles_per_xcd; j += gx) {
+        const int tile = xcd * tiles_per_xcd + j;
+        if (tile >= ntiles) break;
+        const int i0 = tile * TILE + (tid >> 6) * 128 + lane;             // this lane's first point; its second is i0 + 64
+        bool live[2], act[2], defer[2];
+        int orig[2];
+        f32x2 DX, DY, DZ;                                                  // offsets of the lane's two points from the box centre
+        float c0, c1, c2, e0, e1, e2, ps_box;
+        bool wave_any;
+        {
+            f3d_p3 p[2];                                                           // float64 only inside this scope
+            float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int i = i0 + 64 * q;
+                live[q] = i < npts;
+                orig[q] = live[q] ? (perm ? perm[i] : i) : i;                      // caller-order index of this point
+                p[q].x = p[q].y = p[q].z = 0.0;
+                if (live[q]) p[q] = load_point(xyz, (int64_t)(gather_xyz ? orig[q] : i));
+                const double pscale = (fabs(p[q].x) + fabs(p[q].y)) + fabs(p[q].z);
+                act[q] = live[q] & (pscale < 1.0e30);          // float32 work is meaningful (no overflow, no NaN)
+                defer[q] = live[q] & !act[q];                  // this point goes to the next tier
+                const float x32 = (float)p[q].x, y32 = (float)p[q].y, z32 = (float)p[q].z;
+                if (act[q]) {
+                    lo0 = fminf(lo0, x32); hi0 = fmaxf(hi0, x32); lo1 = fminf(lo1, y32); hi1 = fmaxf(hi1, y32);
+                    lo2 = fminf(lo2, z32); hi2 = fmaxf(hi2, z32);
+                }
+            }
+            // ---- (A) bounding box of this wave's live, well-behaved points
+            lo0 = wave_reduce<false>(lo0); hi0 = wave_reduce<true>(hi0);
+            lo1 = wave_reduce<false>(lo1); hi1 = wave_reduce<true>(hi1);
+            lo2 = wave_reduce<false>(lo2); hi2 = wave_reduce<true>(hi2);
+            wave_any = __any(act[0] | act[1]);
+            c0 = 0.5f * (lo0 + hi0); c1 = 0.5f * (lo1 + hi1); c2 = 0.5f * (lo2 + hi2);
+            e0 = 0.5f * (hi0 - lo0) * 1.000002f + 1e-30f; e1 = 0.5f * (hi1 - lo1) * 1.000002f + 1e-30f;
+            e2 = 0.5f * (hi2 - lo2) * 1.000002f + 1e-30f;
+            ps_box = ((fabsf(c0) + fabsf(c1)) + fabsf(c2)) + ((e0 + e1) + e2);
+            // offsets from the box centre (c is a float32, hence exact as a double; the difference is rounded once)
+            DX = (f32x2){(float)(p[0].x - (double)c0), (float)(p[1].x - (double)c0)};
+            DY = (f32x2){(float)(p[0].y - (double)c1), (float)(p[1].y - (double)c1)};
+            DZ = (f32x2){(float)(p[0].z - (double)c2), (float)(p[1].z - (double)c2)};
+        }
+        for (int wd = 0; wd < hdw; ++wd) { hcol0[wd * F3D_BLOCK] = 0u; hcol1[wd * F3D_BLOCK] = 0u; }   // own columns only: no barrier
+        unsigned nvalid[2] = {0u, 0u};
+        unsigned pend[2] = {F3D_CODE_NONE, F3D_CODE_NONE};   // software-pipelined gathers: a code is voted one view (chunk) later
+        unsigned ccode[2][F3D_CHUNK];
+#pragma unroll
+        for (int k = 0; k < F3D_CHUNK; ++k) ccode[0][k] = ccode[1][k] = F3D_CODE_NONE;
+        auto vote = [&](int q, unsigned b) {
+            if (BIN32) vote_bin32(q ? hcol1 : hcol0, b);
+            else vote_coded<WRAP>(nvalid[q], q ? hcol1 : hcol0, b);
+        };
+
+        for (int g = 0; g < ngroups; ++g) {
+            if (ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
+            // lane j <-> view 64g + j: classify the wave's box against that view's planes, project the box centre
+            const int vj = 64 * g + lane;
+            bool box_out = false, box_in = true, own_image = false;
+            float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f, pb3 = 0.f, pb4 = 0.f, pmarg = 0.f;    // (B): n . (c - plane point) per plane, margin
+            if (vj < nviews) {
+                const float* row = ctab + lane * F3D_CULL_ROW;
+                const float marg = 2.0f * __builtin_fmaf(row[20], ps_box, row[21]);
+                float bmax = 0.f, smax = 0.f, base[F3D_NPLANES];
+#pragma unroll
+                for (int m = 0; m < F3D_NPLANES; ++m) {
+                    const float n0 = row[3 * m], n1 = row[3 * m + 1], n2 = row[3 * m + 2];
+                    base[m] = __builtin_fmaf(n0, c0, __builtin_fmaf(n1, c1, __builtin_fmaf(n2, c2, -row[15 + m])));
+                    const float spread = __builtin_fmaf(fabsf(n0), e0, __builtin_fmaf(fabsf(n1), e1, fabsf(n2) * e2));
+                    box_out = box_out | (base[m] + spread < -marg);
+                    box_in = box_in & (base[m] - spread > marg);
+                    bmax = fmaxf(bmax, fabsf(base[m])); smax = fmaxf(smax, spread);
+                }
+                // offset-form cull of a mixed view: a = base + n32 . d.  base itself is the float32 world-coordinate value, off the
+                // real n . (c - pp) by at most marg / 2 (that is what marg bounds); on top of it the float32 offset arithmetic:
+                // 2^-24 (4 |base| + 5 sum |n_j| E_j).
+                pb0 = base[0]; pb1 = base[1]; pb2 = base[2]; pb3 = base[3]; pb4 = base[4];
+                pmarg = 0.5f * marg + 1.01f * (float)F3D_U24 * (4.0f * bmax + 5.0f * smax);
+                own_image = (row[22] == Wf) & (row[23] == Hf);    // the frustum was built for this mask size: inside the planes = inside the image
+            }
+            centre_row mine = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0, 0};
+            bool row_ok = false;
+            if (vj < nviews && !box_out && wave_any) row_ok = centre_precompute(vtab + lane, 64, c0, c1, c2, e0, e1, e2, umaxf, pitch, mine);
+            mine.obase += (unsigned)vj * plane;             // absolute: the view's plane included
+            const unsigned long long valid_m = __ballot(vj < nviews);
+            unsigned long long out_m = __ballot(vj < nviews && box_out);
+            const unsigned long long in_m = __ballot(vj < nviews && box_in && !box_out && own_image);   // whole-wave views without any test
+            const unsigned long long row_m = __ballot(row_ok);
+            if (!wave_any) out_m = valid_m;                 // nothing but deferred / dead lanes in this wave
+            // views whose planes all contain the wave's box: every live lane is inside, no cull, no divergence, no range test.
+            // Taken F3D_CHUNK at a time: project the chunk, retire the previous chunk's votes, then issue the chunk's mask
+            // gathers back to back -- 2 * F3D_CHUNK gathers in flight per wave, each with a whole chunk of arithmetic to land.
+            unsigned long long todo_v = valid_m & ~out_m & in_m & row_m;
+            while (todo_v) {
+                int cbit[F3D_CHUNK]; unsigned coff[2][F3D_CHUNK];
+                bool use[F3D_CHUNK];
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) {
+                    use[k] = todo_v != 0ull;
+                    cbit[k] = use[k] ? __builtin_ctzll(todo_v) : (k ? cbit[0] : 0);   // an unused slot re-reads a valid row and gathers "no sample"
+                    if (use[k]) todo_v &= todo_v - 1ull;
+                }
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) {
+                    const centre_row r = read_row(mine, cbit[k]);
+                    int fi0[2], fi1[2]; bool safe[2];
+                    project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const bool hit = safe[q] & act[q] & use[k];
+                        defer[q] = defer[q] | (!safe[q] & act[q] & use[k]);
+                        coff[q][k] = hit ? r.obase + rel_offset(fi0[q], fi1[q], c_row) : 0u;   // offset 0: a border tile, "no sample"
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) { vote(0, ccode[0][k]); vote(1, ccode[1][k]); }
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = cmasks[coff[0][k]]; ccode[1][k] = cmasks[coff[1][k]]; }
+            }
+#pragma unroll
+            for (int k = 0; k < F3D_CHUNK; ++k) {
+                vote(0, ccode[0][k]); vote(1, ccode[1][k]);
+                ccode[0][k] = ccode[1][k] = F3D_CODE_NONE;
+            }
+            // every other visible view: per-point cull in offset form, image-range test; a lane inside the rounding margin of a
+            // plane, or a view without a usable centre row, sends the point to the next tier
+            todo_v = valid_m & ~out_m & ~(in_m & row_m);
+            while (todo_v) {
+                const int bit = __builtin_ctzll(todo_v);
+                todo_v &= todo_v - 1ull;
+                const int v = 64 * g + bit;
+                const f3d_view& vw = views[v];
+                float nn[F3D_NPLANES][3];                   // wave-uniform: scalar loads, requested together
+#pragma unroll
+                for (int m = 0; m < F3D_NPLANES; ++m) { nn[m][0] = vw.cull_n32[m][0]; nn[m][1] = vw.cull_n32[m][1]; nn[m][2] = vw.cull_n32[m][2]; }
+#pragma unroll
+                for (int m = 0; m < F3D_NPLANES; ++m) { asm volatile("" : "+s"(nn[m][0])); asm volatile("" : "+s"(nn[m][1])); asm volatile("" : "+s"(nn[m][2])); }
+#define F3D_RL1(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), bit))
+                const float bb[F3D_NPLANES] = {F3D_RL1(pb0), F3D_RL1(pb1), F3D_RL1(pb2), F3D_RL1(pb3), F3D_RL1(pb4)};
+                const float mg = F3D_RL1(pmarg);
+#undef F3D_RL1
+                const bool has_row = (row_m >> bit) & 1ull;  // wave-uniform
+                bool maybe[2] = {true, true}, sure[2] = {true, true};
+#pragma unroll
+                for (int m = 0; m < F3D_NPLANES; ++m) {
+                    const f32x2 a = F3D_FMA2(splat2(nn[m][0]), DX, F3D_FMA2(splat2(nn[m][1]), DY, F3D_FMA2(splat2(nn[m][2]), DZ, splat2(bb[m]))));
+                    maybe[0] = maybe[0] & (a.x > -mg); sure[0] = sure[0] & (a.x > mg);
+                    maybe[1] = maybe[1] & (a.y > -mg); sure[1] = sure[1] & (a.y > mg);
+                }
+                unsigned off[2] = {0u, 0u};
+                if (has_row) {
+                    centre_row r = read_row(mine, bit);
+                    const int U8 = __builtin_amdgcn_readlane(mine.U8, bit), V8 = __builtin_amdgcn_readlane(mine.V8, bit);
+                    int fi0[2], fi1[2]; bool safe[2];
+                    project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const bool inside = act[q] & sure[q];
+                        const bool hit = inside & safe[q] & ((unsigned)(fi0[q] + U8) < (unsigned)W) & ((unsigned)(fi1[q] + V8) < (unsigned)H);
+                        defer[q] = defer[q] | (act[q] & maybe[q] & !sure[q]) | (inside & !safe[q]);
+                        off[q] = hit ? r.obase + rel_offset(fi0[q], fi1[q], c_row) : 0u;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) defer[q] = defer[q] | (act[q] & maybe[q]);   // the box comes too close to this view's camera plane
+                }
+                vote(0, pend[0]); vote(1, pend[1]);
+                pend[0] = cmasks[off[0]]; pend[1] = cmasks[off[1]];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            vote(q, pend[q]);
+            uint32_t* hc = q ? hcol1 : hcol0;
+            bool bad = false, trusted = true;
+            if (BIN32) finish_bin32<WRITE_VOTES>(hc, ncodes, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q], classes, votes_out, bad);
+            else trusted = finish_coded<WRITE_VOTES, WRAP>(nvalid[q], hc, words, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q],
+                                                           classes, votes_out, bad);
+            const bool d = defer[q] | (live[q] & !trusted);
+            if (d) todo[atomicAdd(todo_count, 1u)] = gather_xyz ? orig[q] : (i0 + 64 * q);     // index into xyz as this launch sees it
+            if (bad & !d) atomicOr(err, F3D_DEVERR_FUSE);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fuse_mid: the middle tier.  One thread per point that k_fuse deferred (2-5 % of a cloud: the float32 bound leaves a
+// band of ~1e-4 px around every pixel border undecided), every view, float64: float32 cull -> float64 FMA refinement ->
+// fast projection h = M (p - t) (9 FMAs, reciprocal + 2 Newton steps), accepted when farther than
+// 2^-43 (|p-t|_1 |r| (mnorm_k + umax mnorm_2) + umax) from a pixel border (> 10x the distance between this and the
+// canonical operation order).  What it still cannot prove (a point within rounding of a plane or of a pixel border: ~1e-3
+// of the cloud) goes on to k_fuse_exact through the second list.  Same coded masks and vote bins as k_fuse.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cull_point64(const f3d_view& vw, f3d_p3 p, double pscale, bool& maybe, bool& sure) {
+    const double marg = __builtin_fma(vw.cull_rel64, pscale, vw.cull_abs64);
+    bool mb = true, sr = true;
+#pragma unroll
+    for (int m = 0; m < F3D_NPLANES; ++m) {
+        const double a = __builtin_fma(vw.plane_n[m][0], p.x, __builtin_fma(vw.plane_n[m][1], p.y,
+                         __builtin_fma(vw.plane_n[m][2], p.z, -vw.plane_off[m])));
+        mb = mb & (a > -marg);
+        sr = sr & (a > marg);
+    }
+    maybe = mb; sure = sr;
+}
+
+// Returns true when (iu, iv) are proven equal to the canonical floor(u), floor(v) AND lie inside the W x H image; `unsure`
+// is set when the canonical arithmetic has to decide.  umax >= max(W, H): for |u| <= umax the bound is rigorous; beyond it
+// both paths are out of the image anyway.
+__device__ __forceinline__ bool project_fast(const f3d_view& vw, double umax, f3d_p3 p, int W, int H, int& iu, int& iv, bool& unsure) {
+    const double d0 = p.x - vw.t[0], d1 = p.y - vw.t[1], d2 = p.z - vw.t[2];
+    const double h0 = __builtin_fma(vw.M[0], d0, __builtin_fma(vw.M[1], d1, vw.M[2] * d2));
+    const double h1 = __builtin_fma(vw.M[3], d0, __builtin_fma(vw.M[4], d1, vw.M[5] * d2));
+    const double h2 = __builtin_fma(vw.M[6], d0, __builtin_fma(vw.M[7], d1, vw.M[8] * d2));
+    const double r = rcp_newton(h2);
+    const double uf = h0 * r, vf = h1 * r;
+    const double fu = floor(uf), fv = floor(vf);
+    const double c1 = __builtin_fma(umax, vw.mnorm[2], fmax(vw.mnorm[0], vw.mnorm[1]));
+    // |fast - canonical| <= 2^-43 * (|d|_1 |r| (mnorm_k + |u| mnorm_2) + |u|), evaluated with |u| <= umax
+    const double b = F3D_FAST_EPS * __builtin_fma(((fabs(d0) + fabs(d1)) + fabs(d2)) * fabs(r), c1, umax);
+    // frac in (b, 1-b)  <=>  |frac - 0.5| < 0.5 - b      (NaN / inf -> false)
+    const bool safe = (fabs((uf - fu) - 0.5) < 0.5 - b) && (fabs((vf - fv) - 0.5) < 0.5 - b);
+    unsure = !safe;
+    iu = (int)fu; iv = (int)fv;                              // saturating conversions; only used when safe
+    return safe & ((unsigned)iu < (unsigned)W) & ((unsigned)iv < (unsigned)H);
+}
+
+template <typename T, bool WRITE_VOTES>
+__global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xyz, const unsigned int* __restrict__ in_count, const int32_t* __restrict__ in_list,
+                                                         const f3d_view* __restrict__ views, int nviews,
+                                                         const uint8_t* __restrict__ cmasks, int H, int W,
+                                                         int nclasses, int nfilter, const int* __restrict__ fcls, double threshold,
+                                                         int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
+                                                         int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
+                                                         unsigned int* __restrict__ out_count, int32_t* __restrict__ out_list,
+                                                         const f3d_codebook* __restrict__ cb) {
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* lutw = lds_u32;                                             // lut[256] then inv[256] (bytes)
+    uint32_t* hist = lutw + 128;                                          // [words][F3D_BLOCK]
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
+    const uint8_t* inv = lut + 256;
+    const int tid = threadIdx.x;
+    const int words = cb->words;
+    const size_t plane = f3d_coded_plane(H, W);
+    const int wt = f3d_coded_pitch(W);
+    const unsigned none_off = 0u;                                         // a border tile: "no sample"
+    const double umax = (double)(W > H ? W : H);
+    if (tid < 128) lutw[tid] = reinterpret_cast<const uint32_t*>(cb->lut)[tid];
+    __syncthreads();
+    const int count = (int)*in_count;
+    for (int base = blockIdx.x * F3D_BLOCK; base < count; base += gridDim.x * F3D_BLOCK) {
+        const int k = base + tid;
+        const bool live = k < count;
+        const int src = live ? in_list[k] : 0;                                    // index into xyz as k_fuse saw it
+        const int orig = (live && perm && !gather_xyz) ? perm[src] : src;
+        f3d_p3 p = {0.0, 0.0, 0.0};
+        if (live) p = load_point(xyz, (int64_t)src);
+        const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
+        const bool small = pscale < 1.0e30;
+        const float px32 = (float)p.x, py32 = (float)p.y, pz32 = (float)p.z, ps32 = (float)pscale;
+        bool defer = live & !small;
+        for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
+        unsigned nvalid = 0, pend_code = F3D_CODE_NONE;
+        for (int v = 0; v < nviews; ++v) {
+            const f3d_view& vw = views[v];                                        // wave-uniform: scalar loads
+            bool maybe, sure;
+            cull_point32(load_cull(vw), px32, py32, pz32, ps32, small, maybe, sure);
+            bool inside = live & small & sure;
+            if (live & small & maybe & !sure) {                                   // inside the float32 margin: decide with float64 FMAs
+                bool m64, s64;
+                cull_point64(vw, p, pscale, m64, s64);
+                inside = s64;
+                defer = defer | (m64 & !s64);                                     // within rounding of the plane itself
+            }
+            bool hit = false;
+            int iu = 0, iv = 0;
+            if (inside) {
+                bool unsure;
+                hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
+                defer = defer | unsure;
+            }
+            vote_coded<true>(nvalid, hist + tid, pend_code);
+            pend_code = (cmasks + (size_t)v * plane)[hit ? mask_offset<true>(iu, iv, wt) : none_off];
+        }
+        vote_coded<true>(nvalid, hist + tid, pend_code);
+        bool bad = false;
+        const bool trusted = finish_coded<WRITE_VOTES, true>(nvalid, hist + tid, words, lut, inv, nfilter, fcls, nclasses, threshold,
+                                                             live & !defer, orig, classes, votes_out, bad);
+        defer = defer | (live & !trusted);
+        if (defer) out_list[atomicAdd(out_count, 1u)] = src;
+        if (bad & !defer) atomicOr(err, F3D_DEVERR_FUSE);
+    }
+}
+
+// k_fuse_exact: the reference's arithmetic, nothing else, for the points k_fuse deferred (and the whole path of the
+// oracle in kernel form): exact 5-plane test, canonical projection with IEEE divisions, gather, vote, segment.
+template <typename T, int MODE, bool WRITE_VOTES>
+__global__ __launch_bounds__(F3D_BLOCK) void k_fuse_exact(const T* __restrict__ xyz, int64_t n_all, const unsigned int* __restrict__ todo_count,
+                                                           const int32_t* __restrict__ todo,
+                                                           const f3d_view* __restrict__ views, int nviews,
+                                                           const uint8_t* __restrict__ masks, int H, int W,
+                                                           int nclasses, f3d_filter_args flt, double threshold,
+                                                           int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
+                                                           int* __restrict__ err, const int32_t* __restrict__ perm,
+                                                           int gather_xyz) {
+    using HT = hist_traits<MODE>;
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t* hist = lds_u32;
+    const int tid = threadIdx.x;
+    const int ncols = nclasses + 1;
+    const int words = (ncols + 1 + HT::per_word - 1) >> HT::shift;
+    const size_t plane = (size_t)H * (size_t)W;
+    const int64_t count = todo ? (int64_t)*todo_count : n_all;                  // todo == NULL: every point (no fast kernel ran)
+    for (int64_t base = (int64_t)blockIdx.x * F3D_BLOCK; base < count; base += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t k = base + tid;
+        const bool live = k < count;
+        const int64_t src = live ? (todo ? (int64_t)todo[k] : k) : 0;             // index into xyz as k_fuse saw it
+        const int64_t orig = (live && perm && !gather_xyz) ? (int64_t)perm[src] : src;
+        f3d_p3 p = {0.0, 0.0, 0.0};
+        if (live) p = load_point(xyz, src);
+        for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
+        vote_state<MODE> st;
+        for (int v = 0; v < nviews; ++v) {
+            const f3d_view& vw = views[v];
+            bool hit = false;
+            unsigned off = 0u;
+            if (live && f3d_inside_view(vw, p)) {
+                double fu, fv;
+                project_exact(vw, p, fu, fv);
+                if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) {   // NaN compares false
+                    hit = true; off = mask_offset<false>((int)fu, (int)fv, W);
+                }
+            }
+            const int label = hit ? (int)(masks + (size_t)v * plane)[off] : 0;
+            vote_add<MODE>(st, hist, tid, flt, nclasses, hit, label);
+        }
+        if (st.bad) atomicOr(err, F3D_DEVERR_FUSE);
+        finish_point<MODE, WRITE_VOTES>(st, hist, tid, flt, nclasses, threshold, live, orig, classes, votes_out);
+    }
+}
+
+// Audit of the accelerators against the exact arithmetic, every (point, view) pair of a CELL-SORTED cloud: a wave of 64
+// consecutive points forms the box exactly as in k_fuse.  stats[0] pairs inside the frustum, stats[1] pairs the offset
+// projection does not decide (bound, or no usable centre row), stats[2] decided pairs whose pixel differs from the
+// canonical path (must stay 0), stats[3] float32 cull decisions (point or box) the exact plane test contradicts (0).
+template <typename T>
+__global__ __launch_bounds__(F3D_BLOCK) void k_fastpath_audit(const T* __restrict__ xyz, int64_t n,
+                                                               const f3d_view* __restrict__ views, int nviews, int W, int H,
+                                                               unsigned long long* __restrict__ stats) {
+    unsigned long long pairs = 0, fallback = 0, wrong = 0, cullwrong = 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
+    const float umaxf = (float)(W > H ? W : H);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * F3D_BLOCK + threadIdx.x;
+        const bool live = i < n;
+        f3d_p3 p = {0.0, 0.0, 0.0};
+        if (live) p = load_point(xyz, i);
+        const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
+        const bool small = pscale < 1.0e30;
+        const float px32 = (float)p.x, py32 = (float)p.y, pz32 = (float)p.z;
+        float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+        if (live & small) { lo0 = hi0 = px32; lo1 = hi1 = py32; lo2 = hi2 = pz32; }
+        lo0 = wave_reduce<false>(lo0); hi0 = wave_reduce<true>(hi0);
+        lo1 = wave_reduce<false>(lo1); hi1 = wave_reduce<true>(hi1);
+        lo2 = wave_reduce<false>(lo2); hi2 = wave_reduce<true>(hi2);
+        const bool wave_any = __any(live & small);
+        const float c0 = 0.5f * (lo0 + hi0), c1 = 0.5f * (lo1 + hi1), c2 = 0.5f * (lo2 + hi2);
+        const float e0 = 0.5f * (hi0 - lo0) * 1.000002f + 1e-30f, e1 = 0.5f * (hi1 - lo1) * 1.000002f + 1e-30f,
+                    e2 = 0.5f * (hi2 - lo2) * 1.000002f + 1e-30f;
+        const float ps_box = ((fabsf(c0) + fabsf(c1)) + fabsf(c2)) + ((e0 + e1) + e2);
+        const float dx32 = (float)(p.x - (double)c0), dy32 = (float)(p.y - (double)c1), dz32 = (float)(p.z - (double)c2);
+        for (int g = 0; g < (nviews + 63) / 64; ++g) {
+            const int vj = 64 * g + lane;
+            centre_row mine = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0, 0};
+            bool row_ok = false, box_out = false, box_in = true;
+            if (vj < nviews && wave_any) {
+                const f3d_view& vw = views[vj];
+                const float marg = 2.0f * __builtin_fmaf(vw.cull_rel32, ps_box, vw.cull_abs32);
+                for (int m = 0; m < F3D_NPLANES; ++m) {
+                    const float n0 = vw.cull_n32[m][0], n1 = vw.cull_n32[m][1], n2 = vw.cull_n32[m][2];
+                    const float base = __builtin_fmaf(n0, c0, __builtin_fmaf(n1, c1, __builtin_fmaf(n2, c2, -vw.cull_off32[m])));
+                    const float spread = __builtin_fmaf(fabsf(n0), e0, __builtin_fmaf(fabsf(n1), e1, fabsf(n2) * e2));
+                    box_out = box_out | (base + spread < -marg);
+                    box_in = box_in & (base - spread > marg);
+                }
+                row_ok = centre_precompute(reinterpret_cast<const double*>(&vw), 1, c0, c1, c2, e0, e1, e2, umaxf, f3d_coded_pitch(W), mine);
+            }
+            const unsigned long long row_m = __ballot(row_ok), out_m = __ballot(box_out), in_m = __ballot(box_in && !box_out);
+            for (int bit = 0; bit < 64 && 64 * g + bit < nviews; ++bit) {
+                const f3d_view& vw = views[64 * g + bit];
+                const bool in_exact = live && f3d_inside_view(vw, p);
+                bool maybe, sure;
+                cull_point32(load_cull(vw), px32, py32, pz32, (float)pscale, small, maybe, sure);
+                if (live && ((sure && !in_exact) || (!maybe && in_exact))) ++cullwrong;
+                if (live && small && wave_any && ((((out_m >> bit) & 1ull) && in_exact) || (((in_m >> bit) & 1ull) && !in_exact))) ++cullwrong;
+                if (!in_exact) continue;
+                ++pairs;
+                double eu, ev;
+                project_exact(vw, p, eu, ev);
+                const bool ehit = (eu >= 0.0) & (eu < (double)W) & (ev >= 0.0) & (ev < (double)H);
+                if (!((row_m >> bit) & 1ull) || !small) { ++fallback; continue; }
+                centre_row r = read_row(mine, bit);
+                r.U8 = __builtin_amdgcn_readlane(mine.U8, bit); r.V8 = __builtin_amdgcn_readlane(mine.V8, bit);
+                int iu, iv;
+                const bool safe = project_offset(r, dx32, dy32, dz32, iu, iv);
+                if (!safe) { ++fallback; continue; }
+                if (((unsigned)iu < (unsigned)W) & ((unsigned)iv < (unsigned)H)) {      // the tile arithmetic of k_fuse gives the same address
+                    const unsigned off = r.obase + rel_offset(iu - r.U8, iv - r.V8, 64 * f3d_coded_pitch(W) - 64);
+                    if (off != mask_offset<true>(iu, iv, f3d_coded_pitch(W))) ++wrong;
+                }
+                const bool hit = ((unsigned)iu < (unsigned)W) & ((unsigned)iv < (unsigned)H);
+                if (hit != ehit || (hit && !((double)iu == eu && (double)iv == ev))) ++wrong;
+            }
+        }
+    }
+    atomicAdd(&stats[0], pairs); atomicAdd(&stats[1], fallback); atomicAdd(&stats[2], wrong); atomicAdd(&stats[3], cullwrong);
+}
+
+inline int grid_for(int64_t n, int per_block, int cap) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+// =============================================================================================
+// launchers (called from f3d_capi.cpp)
+// =============================================================================================
+#define F3D_GRID_CAP (256 * 8 * 4)      // 256 CUs x 8 blocks, x4 so that tails stay short
+#ifndef F3D_FUSE_GRID
+#define F3D_FUSE_GRID (256 * 4 * 8)     // k_fuse: blocks per launch (multiple of 8; several rounds so that the tail stays short)
+#endif
+
+static size_t fuse_lds_bytes(int hist_dwords_per_point) {           // k_fuse: tables + 2 points per lane x histogram
+    return (64 * F3D_CULL_ROW + 128 + 2 * F3D_VHEAD * 64) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * 2 * F3D_BLOCK * sizeof(uint32_t);
+}
+
+size_t f3d_fuse_lds_bytes(int mode, int nclasses) {                 // LDS of k_fuse_exact
+    const int ncols = nclasses + 1;
+    const int per_word = (mode == MODE_HIST8) ? 4 : 2;
+    return (size_t)((ncols + 1 + per_word - 1) / per_word) * F3D_BLOCK * sizeof(uint32_t);
+}
+
+int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
+    (void)nfilter; (void)want_votes;
+    return nviews <= 255 ? MODE_HIST8 : MODE_HIST16;
+}
+
+size_t f3d_coded_masks_bytes(int nviews, int h, int w) { return (size_t)nviews * f3d_coded_plane(h, w); }
+
+hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, const f3d_filter_args& flt,
+                                 bool want_votes, f3d_codebook* cb, hipStream_t s) {
+    if (nviews <= 0) return hipSuccess;
+    if (nclasses < 0 || nclasses > F3D_CODE_MAX_NCLASSES || ((uintptr_t)dst & 7)) return hipErrorInvalidValue;
+    // which book: the filter's own labels when there are few of them (nothing else is ever looked at, voting.py:121-124);
+    // otherwise the labels that occur in the masks
+    int distinct = 0;
+    if (flt.nfilter > 0 && flt.nfilter <= 8 && !want_votes) {
+        for (int k = 0; k < flt.nfilter; ++k) {
+            bool seen = false;
+            for (int j = 0; j < k; ++j) seen = seen || flt.cls[j] == flt.cls[k];
+            distinct += seen ? 0 : 1;
+        }
+    }
+    const int book = (distinct > 0) ? 2 : 1;
+    const int64_t nbytes = (int64_t)nviews * h * w;
+    if (book == 1) {
+        hipError_t e = hipMemsetAsync(cb->presence, 0, sizeof cb->presence, s);
+        if (e != hipSuccess) return e;
+        const bool vec = !((uintptr_t)src & 7);
+        const dim3 g(grid_for(nbytes >> 3, F3D_BLOCK, 256 * 8)), b(F3D_BLOCK);
+        if (vec) hipLaunchKernelGGL(k_mask_presence<true>, g, b, 0, s, src, nbytes, cb);
+        else hipLaunchKernelGGL(k_mask_presence<false>, g, b, 0, s, src, nbytes, cb);
+    }
+    hipLaunchKernelGGL(k_code_lut, dim3(1), dim3(F3D_BLOCK), 0, s, cb, nclasses, book, flt);
+    const int64_t total = (int64_t)nviews * (int64_t)(f3d_coded_plane(h, w) / 8);
+    const dim3 g(grid_for(total, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+    if (!(w & 7) && !((uintptr_t)src & 7)) hipLaunchKernelGGL(k_code_masks<true>, g, b, 0, s, src, dst, nviews, h, w, cb);
+    else hipLaunchKernelGGL(k_code_masks<false>, g, b, 0, s, src, dst, nviews, h, w, cb);
+    return hipGetLastError();
+}
+
+template <typename KernelT>
+static hipError_t raise_lds(KernelT kernel, size_t lds) {
+    if (lds <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <typename T, bool V>
+static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* views_dev, int nviews, const uint8_t* masks, const uint8_t* cmasks,
+                                int h, int w, int nclasses, const f3d_filter_args& flt, double threshold, int64_t* classes, uint16_t* votes,
+                                int* err, const int32_t* perm, bool gather_xyz, unsigned int* todo_count, int32_t* todo,
+                                unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, int mode, int grid, hipStream_t s) {
+    const bool fast = cmasks != nullptr;                     // no coded masks (nclasses > F3D_CODE_MAX_NCLASSES): exact kernel only
+    if (fast && (n > 0x7ffff000LL || (flt.nfilter > 0 && !flt.cls_dev) || (uint64_t)nviews * f3d_coded_plane(h, w) >= (1ull << 32)))
+        return hipErrorInvalidValue;                         // 32-bit point indices and mask offsets; filter list in device memory
+    const dim3 g(grid), b(F3D_BLOCK), ge(fast ? 512 : grid);
+    const int words_max = (nclasses + 1 + 2 + 3) >> 2;      // every label 0..nclasses present, plus the codes "no sample" and "rejected"
+    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES), lds_full = fuse_lds_bytes(words_max);
+    const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses);
+    if (lds_exact > 160 * 1024 || lds_full > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e;
+    if (fast) {
+        const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
+        auto ks = k_fuse<T, V, true, false>;                 // dword bins: at most F3D_BIN32_MAX_CODES codes
+        auto kf = wrap ? k_fuse<T, V, false, true> : k_fuse<T, V, false, false>;   // 8-bit bins, 4 per dword: any alphabet
+        if ((e = raise_lds(ks, lds_small)) != hipSuccess || (e = raise_lds(kf, lds_full)) != hipSuccess) return e;
+        // two instances are enqueued; the code book on the device says which one runs, the other returns at once
+        hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
+                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES);
+        hipLaunchKernelGGL(kf, g, b, lds_full, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
+                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 256);
+        // middle tier: the deferred points again, in float64; what it cannot prove either lands in the second list
+        auto km = k_fuse_mid<T, V>;
+        const size_t lds_mid = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
+        if ((e = raise_lds(km, lds_mid)) != hipSuccess) return e;
+        hipLaunchKernelGGL(km, dim3(1024), b, lds_mid, s, (const T*)xyz, todo_count, todo, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
+                           flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo2_count, todo2, cb);
+    }
+    if (mode == MODE_HIST8) {
+        auto ke = k_fuse_exact<T, MODE_HIST8, V>;
+        if ((e = raise_lds(ke, lds_exact)) != hipSuccess) return e;
+        hipLaunchKernelGGL(ke, ge, b, lds_exact, s, (const T*)xyz, n, todo2_count, fast ? todo2 : nullptr, views_dev, nviews, masks, h, w, nclasses,
+                           flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0);
+    } else {
+        auto ke = k_fuse_exact<T, MODE_HIST16, V>;
+        if ((e = raise_lds(ke, lds_exact)) != hipSuccess) return e;
+        hipLaunchKernelGGL(ke, ge, b, lds_exact, s, (const T*)xyz, n, todo2_count, fast ? todo2 : nullptr, views_dev, nviews, masks, h, w, nclasses,
+                           flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0);
+    }
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                           const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
+                           double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
+                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, hipStream_t s) {
+    // todo_count points at 4 counters (first list, second list, 2 spare) followed by the two index lists of n entries each
+    if (n <= 0) return hipSuccess;
+    unsigned int* todo2_count = todo_count + 1;
+    int32_t* todo2 = todo + n;
+    const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);      // bins of the exact kernel; the fast one uses 8 bits
+    const int64_t ntiles = (n + F3D_BLOCK * 2 - 1) / (F3D_BLOCK * 2);          // k_fuse: 2 points per lane
+    int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID);
+    grid = (grid + 7) & ~7;                                  // the XCD-aware tile mapping needs a multiple of 8 blocks
+    if (cmasks) {
+        hipError_t e0 = hipMemsetAsync(todo_count, 0, 4 * sizeof(unsigned int), s);
+        if (e0 != hipSuccess) return e0;
+    }
+#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, mode, grid, s
+    if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true>(F3D_ARGS) : launch_fuse_t<double, false>(F3D_ARGS);
+    return votes ? launch_fuse_t<float, true>(F3D_ARGS) : launch_fuse_t<float, false>(F3D_ARGS);
+#undef F3D_ARGS
+}
+
+hipError_t f3d_launch_fastpath_audit(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews, int w, int h,
+                                     unsigned long long* stats_dev, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(stats_dev, 0, 4 * sizeof(unsigned long long), s);
+    if (e != hipSuccess || n <= 0) return e;
+    const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
+    if (dtype == F3D_F64) hipLaunchKernelGGL(k_fastpath_audit<double>, g, b, 0, s, (const double*)xyz, n, views_dev, nviews, w, h, stats_dev);
+    else hipLaunchKernelGGL(k_fastpath_audit<float>, g, b, 0, s, (const float*)xyz, n, views_dev, nviews, w, h, stats_dev);
+    return hipGetLastError();
+}

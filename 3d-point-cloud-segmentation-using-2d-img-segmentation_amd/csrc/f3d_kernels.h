@@ -42,6 +42,14 @@ struct f3d_filter_args {                   // filter_classes of VotingSegmentati
     const int* cls_dev;                    // device copy of the list when nfilter > 8
 };
 
+// device-resident code book of the fused path's vote bins (built per call by k_mask_presence + k_code_lut, f3d_fuse.hip)
+struct f3d_codebook {
+    uint8_t lut[256];                      // label -> bin code (0 = no sample / absent label, 1 = rejected label, ...)
+    uint8_t inv[256];                      // bin code -> label (must follow lut directly: the kernels stage both with one copy)
+    int ncodes, words, book, pad;          // bins in use, histogram dwords per thread = (ncodes + 3) / 4, 1 presence / 2 filter book
+    unsigned presence[8];                  // bit l: label l occurs in the masks
+};
+
 hipError_t f3d_launch_clear_error_bits(int* err, int bits, hipStream_t s);
 hipError_t f3d_launch_rotate(const double* xyz, int64_t n, const double q[4], double* out, hipStream_t s);
 hipError_t f3d_launch_unproject_depth(const void* depth, int depth_type, int h, int w, const double K[9], double scale,
@@ -61,14 +69,16 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
                            double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
-                           unsigned int* todo_count, int32_t* todo, hipStream_t s);
+                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, hipStream_t s);
 // masks [V,H,W] row-major labels -> 8x8-pixel tiles of vote-bin codes (any H, W); dst holds f3d_coded_masks_bytes()
 size_t f3d_coded_masks_bytes(int nviews, int h, int w);
-hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, hipStream_t s);
+// (builds the code book `cb` first: from filter_classes when it is short and no vote rows are wanted, else from the labels present)
+hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, const f3d_filter_args& flt,
+                                 bool want_votes, f3d_codebook* cb, hipStream_t s);
 // audit of the fast projection (tests only): for every (point, view) pair inside the frustum counts
 // stats[0] pairs, stats[1] pairs sent to the exact fallback, stats[2] accepted pairs whose floor differs from the
 // canonical path (must stay 0), stats[3] pairs rejected/accepted by the f32 cull that the exact test contradicts (0)
-hipError_t f3d_launch_fastpath_audit(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
+hipError_t f3d_launch_fastpath_audit(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews, int w, int h,
                                      unsigned long long* stats_dev, hipStream_t s);
 // cell sort (f3d_sort.hip): perm (and sorted_xyz unless NULL) receive the cloud in grid-cell order; scratch >= f3d_sort_scratch_bytes(n)
 size_t f3d_sort_scratch_bytes(int64_t n);

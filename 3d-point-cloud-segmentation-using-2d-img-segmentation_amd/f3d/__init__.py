@@ -21,7 +21,7 @@ __all__ = ['F3DError', 'F3DUnavailable', 'Context', 'default_context', 'library'
 F64, F32 = 0, 1
 FUSE_SORT, FUSE_GATHER = 2, 4
 OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_ZERO_QUAT, ERR_NOMEM = 0, -1, -2, -3, -4, -5
-VIEW_DOUBLES = 80            # sizeof(f3d_view) / 8
+VIEW_DOUBLES = 88            # sizeof(f3d_view) / 8
 OBB_DOUBLES = 15             # sizeof(f3d_obb) / 8
 MAX_OBB = 4096
 
@@ -82,7 +82,8 @@ def library():
         'f3d_project_view_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),
         'f3d_project_vote_argmax': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp]),
         'f3d_project_vote_argmax_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp, C.c_uint, vp, vp]),
-        'f3d_debug_fastpath_audit': (i32, [vp, vp, i32, i64, vp, i32, vp]),
+        'f3d_debug_fastpath_audit': (i32, [vp, vp, i32, i64, vp, i32, i32, i32, vp]),
+        'f3d_debug_fuse_deferred': (i32, [vp, vp, vp]),
         'f3d_cloud_sort_cells_dev': (i32, [vp, vp, i32, i64, vp, vp, vp]),
         'f3d_take_device_error': (i32, [vp, vp]),
         'f3d_vote_uv2pt': (i32, [vp, vp, vp, i64, vp, i64, i32]),
@@ -172,7 +173,7 @@ def frustum_data(K, w, h, wxyzs, translations):
 
 
 def views_build(K, w, h, wxyzs, translations, max_depth):
-    """Packed per-view records (640 bytes each, viewed as float64 [V, 80]) consumed by the fused kernels."""
+    """Packed per-view records (704 bytes each, viewed as float64 [V, 88]) consumed by the fused kernels."""
     K = _f64(K, (3, 3))
     q = _f64(np.atleast_2d(wxyzs))
     t = _f64(np.atleast_2d(translations))
@@ -187,11 +188,11 @@ def views_build(K, w, h, wxyzs, translations, max_depth):
 
 
 def view_fields(views):
-    """Named sub-arrays of a [V,80] view table (for tests and debugging)."""
+    """Named sub-arrays of a [V,88] view table (for tests and debugging)."""
     v = np.asarray(views)
     return {'M': v[:, 0:9].reshape(-1, 3, 3), 't': v[:, 9:12], 'mnorm': v[:, 12:15],
-            'K': v[:, 32:41].reshape(-1, 3, 3), 'qinv': v[:, 41:45],
-            'plane_pt': v[:, 45:60].reshape(-1, 5, 3), 'plane_n': v[:, 60:75].reshape(-1, 5, 3), 'plane_off': v[:, 75:80]}
+            'K': v[:, 40:49].reshape(-1, 3, 3), 'qinv': v[:, 49:53],
+            'plane_pt': v[:, 53:68].reshape(-1, 5, 3), 'plane_n': v[:, 68:83].reshape(-1, 5, 3), 'plane_off': v[:, 83:88]}
 
 
 def _xyz(points):
@@ -482,13 +483,19 @@ class Context:
     def cloud_sort_cells_dev(self, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream=None):
         self._check(self._lib.f3d_cloud_sort_cells_dev(self._h, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream))
 
-    def fastpath_audit(self, points, views):
-        """(pairs inside, pairs sent to the exact fallback, accepted-but-different pairs, contradicted culls)."""
+    def fastpath_audit(self, points, views, w=1024, h=1024):
+        """(pairs inside, pairs left to the exact kernel, decided-but-different pairs, contradicted culls) on the cell-sorted cloud."""
         p, dt = _xyz(points)
         v = _f64(views)
         stats = np.zeros(4, np.uint64)
-        self._check(self._lib.f3d_debug_fastpath_audit(self._h, _ptr(p), dt, len(p), _ptr(v), len(v), _ptr(stats)))
+        self._check(self._lib.f3d_debug_fastpath_audit(self._h, _ptr(p), dt, len(p), _ptr(v), len(v), int(w), int(h), _ptr(stats)))
         return tuple(int(x) for x in stats)
+
+    def fuse_deferred(self, stream=None):
+        """(points the float32 kernel deferred to the float64 tier, points that went on to the exact kernel) of the last fused call."""
+        c = np.zeros(2, np.uint32)
+        self._check(self._lib.f3d_debug_fuse_deferred(self._h, stream, _ptr(c)))
+        return int(c[0]), int(c[1])
 
     def take_device_error(self, stream=None):
         self._check(self._lib.f3d_take_device_error(self._h, stream))

@@ -56,7 +56,7 @@ def parse():
 
 def algorithmic_bytes(n, v, h, w, xyz_bytes):
     """xyz read once + masks read once + int64 classes written + view records."""
-    return xyz_bytes * n + v * h * w + 8 * n + 424 * v
+    return xyz_bytes * n + v * h * w + 8 * n + 704 * v
 
 
 def time_kernel(torch, fn, iters, stream):
@@ -233,6 +233,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ctx.take_device_error(stream.cuda_stream)
+    deferred = ctx.fuse_deferred(stream.cuda_stream)        # (to the float64 tier, to the exact kernel) in the last step
 
     # dominant kernel alone (k_fuse), HIP events on its launch stream, same resident inputs: with the in-step
     # sort the step is [sort kernels][k_fuse reading xyz through perm]; both parts are timed on their own.
@@ -281,6 +282,7 @@ def main():
                    config=dict(workload=f'C3: {n} points/GPU x {V} ring views, {S}x{S} {args.masks} uint8 masks, '
                                         f'nclasses=133, threshold=0.5, filter_classes={flt}; fused project->sample->vote->segment',
                                points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64', cloud_layout=layout,
+                               deferred_points=dict(to_float64_tier=deferred[0], to_exact_kernel=deferred[1]),
                                exchange='none' if not use_dist else f'RCCL all_gather of {V // world} masks/rank per step, double-buffered and overlapped with the previous step'),
                    roofline=roofline)
 

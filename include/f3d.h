@@ -57,7 +57,7 @@ typedef enum f3d_dtype {
     F3D_F32 = 1                   /* xyz stored as float32 [N,3]; widened to f64 in registers     */
 } f3d_dtype;
 
-/* One camera view, in the form the kernels consume (8-byte aligned, 640 bytes = 80 doubles).
+/* One camera view, in the form the kernels consume (8-byte aligned, 704 bytes = 88 doubles).
  * Built on the host by f3d_views_build(); the fused kernel reads it through scalar loads and
  * stages the float32 cull planes in LDS.
  *   exact data (the reference's arithmetic uses exactly these):  K, qinv, t, plane_pt, plane_n
@@ -68,7 +68,11 @@ typedef enum f3d_dtype {
  *                     arithmetic (camera_utils.py:21-25 order) is evaluated.
  *     cull_*32      : float32 copy of the planes, a = n32 . p32 - off32; a point (or a whole tile's
  *                     bounding box) is accepted/rejected without the exact plane test only when |a|
- *                     exceeds rel32 * (|x|+|y|+|z|) + abs32. */
+ *                     exceeds rel32 * (|x|+|y|+|z|) + abs32.
+ *     M32           : (float)M, the operator of the float32 "centre + offset" projection: one lane per view
+ *                     projects the centre c of a wavefront's bounding box with M in float64, every lane then
+ *                     only needs the float32 offset term M32 (p - c); accepted when farther than a rigorous
+ *                     bound from a pixel border, otherwise the point goes to the exact kernel. */
 typedef struct f3d_view {
     /* hot (128 B = two scalar-cache lines): everything the fast projection reads */
     double M[9];                  /* K * Rot(qinv), row-major                                     */
@@ -80,9 +84,13 @@ typedef struct f3d_view {
     float  cull_off32[F3D_NPLANES];
     float  cull_rel32;
     float  cull_abs32;
-    double cull_rel64;            /* float64 refinement of the point cull for lanes inside the float32 margin:   */
+    float  img_w;                 /* the image the frustum planes were built for (f3d_views_build's w, h)         */
+    float  img_h;
+    double cull_rel64;            /* float64 refinement of the point cull (middle tier):                          */
     double cull_abs64;            /* a = n . p - plane_off in FMAs; |a| <= rel64 * |p|_1 + abs64 -> exact kernel   */
-    float  pad1[6];
+    float  pad1[4];
+    float  M32[9];                /* (float)M[k]                                                                  */
+    float  pad2[7];
     /* exact data: what the reference's arithmetic uses */
     double K[9];                  /* intrinsics, row-major (camera_utils.py:23)                   */
     double qinv[4];               /* conj(q)/|q|^2 (w,x,y,z)  (camera_utils.py:22)                */
@@ -173,10 +181,11 @@ int f3d_project_vote_argmax(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
  *                     caller's order.  `perm` must be NULL.
  *   F3D_FUSE_GATHER   with `perm`: xyz is still the caller-order cloud and the kernel reads point
  *                     perm[i] (what F3D_FUSE_SORT does internally; lets a caller time / reuse the sort).
- * Every call first copies the masks into context scratch as 8x8-pixel tiles (one cache line each) of vote-bin
- * codes -- one extra pass over V*H*W bytes; the 1-byte gathers of neighbouring points then share lines in both
- * image directions.  With nclasses > 253 (no byte left for the "no sample" and "rejected label" codes) the
- * accelerated kernel is skipped and the reference-arithmetic kernel labels every point.
+ * Every call first finds the labels that occur in the masks and copies the masks into context scratch as 8x8-pixel
+ * tiles (one cache line each) of vote-bin codes -- two passes over V*H*W bytes; the 1-byte gathers of neighbouring
+ * points then share lines in both image directions, and a thread's vote histogram only has bins for labels that
+ * exist.  With nclasses > 253 (no byte left for the "no sample" and "rejected label" codes) the accelerated kernel
+ * is skipped and the reference-arithmetic kernel labels every point.
  * perm (device, may be NULL): perm[i] is the caller-order index of the i-th point in cell order
  * (from f3d_cloud_sort_cells_dev); without F3D_FUSE_GATHER xyz must be the sorted copy.
  * classes/votes are always written at caller-order indices. */
@@ -188,13 +197,16 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
                                 int nclasses, const int32_t* filter /*host*/, int nfilter,
                                 double threshold, int64_t* classes, uint16_t* votes_u16,
                                 unsigned flags, const int32_t* perm, void* stream);
-/* Test hook: evaluates, for every (point, view) pair, the accelerated decisions of the fused
- * kernel next to the exact arithmetic.  stats[0] = pairs inside the frustum, stats[1] = pairs the
- * fast projection hands to the exact fallback, stats[2] = accepted pairs whose pixel differs from
- * the canonical path (must be 0), stats[3] = float32 cull decisions the exact plane test
- * contradicts (must be 0).  Host pointers. */
+/* Test hook: cell-sorts the cloud and evaluates, for every (point, view) pair, the accelerated decisions of the
+ * fused kernel (wave-box and per-point float32 culls, centre + offset projection for a w x h image) next to the exact
+ * arithmetic.  stats[0] = pairs inside the frustum, stats[1] = pairs the offset projection leaves to the exact
+ * kernel, stats[2] = decided pairs whose pixel differs from the canonical path (must be 0), stats[3] = float32 cull
+ * decisions the exact plane test contradicts (must be 0).  Host pointers. */
 int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
-                             const f3d_view* views, int nviews, uint64_t stats[4]);
+                             const f3d_view* views, int nviews, int w, int h, uint64_t stats[4]);
+/* Diagnostic: how many points of the last fused call of this context the float32 kernel handed to the float64 middle
+ * tier (counts[0]) and how many of those went on to the reference-arithmetic kernel (counts[1]).  Synchronises `stream`. */
+int f3d_debug_fuse_deferred(f3d_ctx* ctx, void* stream, uint32_t counts[2]);
 /* Sort of the cloud by coarse grid cell: perm (int32 [n], caller-order index of sorted point i)
  * and, unless NULL, sorted_xyz (same dtype/size as xyz); device buffers owned by the caller. */
 int f3d_cloud_sort_cells_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,

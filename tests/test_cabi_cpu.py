@@ -33,7 +33,7 @@ def test_view_record_layout_matches_header():
                   for m in re.finditer(r'\b(double)\s+\w+((?:\[\w+\])*);', body))
     floats = sum(int(np.prod([int(x) if x.isdigit() else 5 for x in re.findall(r'\[(\w+)\]', m.group(2))] or [1]))
                  for m in re.finditer(r'\b(float)\s+\w+((?:\[\w+\])*);', body))
-    assert doubles * 8 + floats * 4 == f3d.VIEW_DOUBLES * 8 == 640
+    assert doubles * 8 + floats * 4 == f3d.VIEW_DOUBLES * 8 == 704
 
 
 def test_views_build_equals_oracle_bit_for_bit(golden):

@@ -273,12 +273,15 @@ def test_fast_projection_and_f32_cull_never_disagree_with_exact(ctx):
               rng.uniform([-5, -5, 0], [5, 5, 3], (200_000, 3)),               # full f64 mantissas
               t[rng.integers(0, len(t), 50_000)] + rng.normal(size=(50_000, 3)) * 1e-3,   # hugging the eyes (z -> 0)
               np.vstack([_near_pixel_boundary_points(K, q[j], t[j], rng, 4000, sc['w'], sc['h']) for j in range(0, 64, 4)])]
-    fallbacks = 0
-    for pts in clouds:
-        pairs, fb, wrong, cullwrong = ctx.fastpath_audit(pts, views)
-        assert pairs > 0 and wrong == 0 and cullwrong == 0, (pairs, fb, wrong, cullwrong)
-        fallbacks += fb
-    assert fallbacks > 0                                                       # the fallback branch really runs
+    fallbacks = decided = 0
+    for k, pts in enumerate(clouds):
+        for dim in (1024, 16):                                                 # a tiny image exercises the out-of-image rule as well
+            pairs, fb, wrong, cullwrong = ctx.fastpath_audit(pts, views, dim, dim)
+            assert pairs > 0 and wrong == 0 and cullwrong == 0, (k, dim, pairs, fb, wrong, cullwrong)
+            fallbacks += fb; decided += pairs - fb
+    assert fallbacks > 0 and decided > 0                                       # both branches really run
+    pairs, fb, wrong, cullwrong = ctx.fastpath_audit(synth.cloud(4_000_000), views, 1024, 1024)   # a cloud as dense as C3's cells assume
+    assert wrong == 0 and cullwrong == 0 and fb < 0.01 * pairs, (pairs, fb)    # per pair the float32 bound leaves < 1 % undecided
     # ... and the fused kernel agrees with the oracle on the adversarial sets
     pts = np.vstack([c[:20000] for c in clouds])
     with np.errstate(all='ignore'):
