@@ -18,6 +18,7 @@ from pathlib import Path
 import numpy as np
 
 import f3d
+from f3d import sharding
 
 
 def obb_from_points(pts):
@@ -98,51 +99,215 @@ def update_id_info(id1, int_bb, info_sem, id_info_per_point):
     return info_sem, id_info_per_point
 
 
-class _MergeState:
-    """Book-keeping that turns the reference's O(B^2) full-cloud rescans into exact incremental updates:
-    member index lists per id (kept in ascending point order, so every box is fitted on exactly the array
-    ``pcd_points[ids == id]`` the reference would build), cached boxes with their axis-aligned bounds, and the
-    cloud resident on the GPU for the whole merge."""
+class HipCloud:
+    """The cloud resident on the GPU for one merge: grouping by instance id, hull candidates and point-in-box scans through
+    libf3d_hip (f3d_group_by_id*, f3d_obb_extremes*, f3d_obb_hull_filter*, f3d_points_in_obb*).  With torch the arrays stay on
+    the device across the calls; without it the host-pointer entry points upload what they need (the context keeps the cloud
+    between the three grouping calls).  `point_range` = the [lo, hi) share of the points this process scans (sharded merge)."""
 
-    def __init__(self, pts, ids, box_fn):
-        self.pts, self.ids, self.box_fn = pts, ids, box_fn
-        self.prof = {'group': 0.0, 'fit': 0.0, 'nfit': 0, 'scan': 0.0, 'nscan': 0, 'absorb': 0.0, 'upload': 0.0}
-        t0 = time.perf_counter()
-        order = np.argsort(ids, kind='stable')
-        uniq, start = np.unique(ids[order], return_index=True)
-        bounds = np.append(start, len(order))
-        self.members = {int(u): order[bounds[k]:bounds[k + 1]] for k, u in enumerate(uniq)}
-        self.prof['group'] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        self.boxes = {}
+    def __init__(self, pts, point_range=None):
+        self.pts = pts
+        self.n = len(pts)
+        self.lo, self.hi = (0, self.n) if point_range is None else point_range
         self.ctx = f3d.default_context()
-        self.dev = None
+        self.torch = None
         try:
             import torch
             if torch.cuda.is_available():
                 self.torch = torch
                 self.device = torch.device('cuda', self.ctx.device)
-                self.dev = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float64)).to(self.device)
                 self.stream = torch.cuda.Stream(self.device)
-                torch.cuda.synchronize(self.device)
+                with torch.cuda.stream(self.stream):
+                    self.dev = torch.from_numpy(pts).to(self.device)
+                self.stream.synchronize()
         except ImportError:
             pass
+
+    def group(self, ids, nids):
+        """(order int32 [n], starts int64 [nids + 2]) -- members of every id in ascending point index."""
+        if self.torch is None:
+            return self.ctx.group_by_id(ids, nids)
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            dids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+            self.d_order = torch.empty(self.n, dtype=torch.int32, device=self.device)
+            self.d_keys = torch.empty(self.n, dtype=torch.int32, device=self.device)
+            self.d_starts = torch.empty(nids + 2, dtype=torch.int64, device=self.device)
+            self.ctx.group_by_id_dev(dids.data_ptr(), self.n, nids, self.d_order.data_ptr(), self.d_keys.data_ptr(), self.d_starts.data_ptr(),
+                                     self.stream.cuda_stream)
+            self.stream.synchronize()
+            self.nids = nids
+            return self.d_order.cpu().numpy(), self.d_starts.cpu().numpy()
+
+    def extremes(self):
+        if self.torch is None:
+            return self.ctx.obb_extremes(self.pts)
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            out = torch.empty((self.nids, 26), dtype=torch.int32, device=self.device)
+            self.ctx.obb_extremes_dev(self.dev.data_ptr(), f3d.F64, self.n, self.d_order.data_ptr(), self.d_keys.data_ptr(), self.nids,
+                                      out.data_ptr(), self.stream.cuda_stream)
+            self.stream.synchronize()
+            return out.cpu().numpy()
+
+    def hull_filter(self, fstart, facets, margin):
+        if self.torch is None:
+            return self.ctx.obb_hull_filter(fstart, facets, margin)
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            dfs = torch.from_numpy(np.ascontiguousarray(fstart, dtype=np.int32)).to(self.device)
+            deq = torch.from_numpy(np.ascontiguousarray(facets, dtype=np.float64).reshape(-1, 4)).to(self.device)
+            dmg = torch.from_numpy(np.ascontiguousarray(margin, dtype=np.float64)).to(self.device)
+            cand = torch.empty(max(self.n, 1), dtype=torch.int32, device=self.device)
+            cnt = torch.empty(max(self.nids, 1), dtype=torch.int32, device=self.device)
+            self.ctx.obb_hull_filter_dev(self.dev.data_ptr(), f3d.F64, self.n, self.d_order.data_ptr(), self.d_keys.data_ptr(),
+                                         self.d_starts.data_ptr(), self.nids, dfs.data_ptr(), deq.data_ptr() if len(deq) else None, dmg.data_ptr(),
+                                         cand.data_ptr(), cnt.data_ptr(), self.stream.cuda_stream)
+            self.stream.synchronize()
+            return cand.cpu().numpy()[:self.n], cnt.cpu().numpy()[:self.nids]
+
+    def cooccurrence(self, packed):
+        """uint8 [B, B]: some point of this process's share lies in both boxes (rows of `packed`, float64 [B, 15])."""
+        B = len(packed)
+        if self.hi <= self.lo:
+            return np.zeros((B, B), np.uint8)
+        if self.torch is None:
+            _, cooc = self.ctx.points_in_obb(self.pts[self.lo:self.hi], packed, want_bits=False, want_cooc=True)
+            return cooc.astype(np.uint8)
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            cd = torch.empty((B, B), dtype=torch.uint8, device=self.device)
+            self.ctx.points_in_obb_dev(self.dev.data_ptr() + 24 * self.lo, f3d.F64, self.hi - self.lo, packed, None, cd.data_ptr(),
+                                       self.stream.cuda_stream)
+            self.stream.synchronize()
+            return cd.cpu().numpy()
+
+
+def _all_gather_rows(dist, mine):
+    """Every rank's float64 array `mine` (same shape everywhere) -> list of all of them, bit for bit."""
+    import torch
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [x.cpu().numpy() for x in parts]
+
+
+class _MergeState:
+    """Book-keeping that turns the reference's O(B^2) full-cloud rescans and refits into exact incremental updates:
+    * the points of every id in ascending point order (one GPU sort, not a 50M-entry host argsort), so that a box is fitted on
+      exactly the array ``pcd_points[ids == id]`` the reference would build -- minus the members that provably lie strictly
+      inside the hull of the instance's 26 directional extremes (dropped by a GPU pass): hull, hull vertices and box are the
+      same, Qhull sees a few hundred points instead of ~10^4;
+    * cached boxes with their axis-aligned bounds, refitted only after a merge (on the union of the two candidate lists);
+    * the cloud resident on the GPU for the whole merge.
+    Sharded (``dist`` = an initialised torch.distributed module): every rank holds the arrays, scans only its contiguous share
+    of the points and combines every co-occurrence answer with one all_reduce(MAX); the initial box fits are dealt out by
+    instance (id mod world) and exchanged with one all_gather.  The control flow runs identically on every rank."""
+
+    PREFILTER_MIN = 256                                   # instances smaller than this are fitted on all of their points
+
+    def __init__(self, pts, ids, box_fn, dist=None, backend=None):
+        self.pts, self.ids, self.box_fn, self.dist = pts, ids, box_fn, dist
+        self.prof = {'group': 0.0, 'prefilter': 0.0, 'fit': 0.0, 'nfit': 0, 'scan': 0.0, 'nscan': 0, 'absorb': 0.0, 'upload': 0.0, 'exchange': 0.0}
+        n = len(pts)
+        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+        share = (n * self.rank // self.world, n * (self.rank + 1) // self.world)
+        t0 = time.perf_counter()
+        self.cloud = backend(pts, share) if backend is not None else HipCloud(pts, share)
         self.prof['upload'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ids_ok = n > 0 and int(ids.min()) >= 0 and int(ids.max()) < 2 ** 30
+        self.nids = int(ids.max()) + 1 if ids_ok else 0
+        if ids_ok:
+            order, starts = self.cloud.group(ids, self.nids)
+            self.members = {k: [order[starts[k]:starts[k + 1]]] for k in range(self.nids) if starts[k + 1] > starts[k]}
+        else:                                             # negative or huge ids: plain NumPy grouping (no prefilter either)
+            order = np.argsort(ids, kind='stable')
+            uniq, start = np.unique(ids[order], return_index=True)
+            bounds = np.append(start, n)
+            self.members = {int(u): [order[bounds[k]:bounds[k + 1]]] for k, u in enumerate(uniq)}
+        self.counts = {k: len(v[0]) for k, v in self.members.items()}
+        self.cands = {k: v[0] for k, v in self.members.items()}       # hull candidates: ascending point indices, a superset of the hull's vertices
+        self.prof['group'] = time.perf_counter() - t0
+        if ids_ok:
+            t0 = time.perf_counter()
+            self._prefilter(starts)
+            self.prof['prefilter'] = time.perf_counter() - t0
+        self.boxes, self.failed = {}, {}
+        if dist is not None:
+            self._fit_all_sharded()
+
+    def _prefilter(self, starts):
+        """Drop, per instance, the members strictly inside the hull of its directional extremes (exact: see HipCloud / f3d.h)."""
+        from scipy.spatial import ConvexHull, QhullError
+        big = [k for k, c in self.counts.items() if c >= self.PREFILTER_MIN]
+        if not big or not hasattr(self.cloud, 'extremes'):
+            return
+        ext = self.cloud.extremes()
+        fstart = np.zeros(self.nids + 1, np.int32)
+        margin = np.zeros(self.nids)
+        eqs, nf = [], np.zeros(self.nids, np.int64)
+        for k in big:
+            e = np.unique(ext[k][ext[k] >= 0])
+            if len(e) < 4:
+                continue
+            p = self.pts[e]
+            try:
+                eq = ConvexHull(p).equations                              # n . x + o <= 0 inside, |n| = 1
+            except QhullError:
+                continue                                                  # flat / degenerate extremes: keep every member
+            eqs.append(eq); nf[k] = len(eq)
+            margin[k] = 1e-9 * (np.abs(p).max() + 1.0)
+        fstart[1:] = np.cumsum(nf)
+        if not eqs:
+            return
+        facets = np.concatenate(eqs)
+        cand, cnt = self.cloud.hull_filter(fstart, facets, margin)
+        for k in big:
+            if nf[k]:
+                self.cands[k] = np.sort(cand[starts[k]:starts[k] + cnt[k]])
 
     def count(self, i):
-        m = self.members.get(int(i))
-        return 0 if m is None else len(m)
+        return self.counts.get(int(i), 0)
+
+    def _fit(self, i):
+        t0 = time.perf_counter()
+        c, R, e = self.box_fn(self.pts[self.cands[i]])
+        corners = obb_corners(c, R, e)
+        pad = 1e-9 * (np.abs(corners).max() + np.abs(e).max() + 1.0)           # the in-box test rounds; never prune a touching pair
+        self.prof['fit'] += time.perf_counter() - t0; self.prof['nfit'] += 1
+        return (np.asarray(c, np.float64), np.asarray(R, np.float64), np.asarray(e, np.float64), corners.min(0) - pad, corners.max(0) + pad)
+
+    def _fit_all_sharded(self):
+        """Initial boxes of all instances with >= 4 points, dealt out by id mod world, exchanged bit for bit."""
+        t0 = time.perf_counter()
+        ids = sorted(k for k, c in self.counts.items() if c >= 4)
+        mine = np.zeros((len(ids), 22))                                        # c 3, R 9, e 3, lo 3, hi 3, ok 1
+        for j, k in enumerate(ids):
+            if j % self.world == self.rank:
+                try:
+                    c, R, e, lo, hi = self._fit(k)
+                    mine[j] = np.concatenate([c, R.reshape(-1), e, lo, hi, [1.0]])
+                except Exception as exc:                                       # raised again if (and when) the flow asks for this box
+                    self.failed[k] = exc
+                    mine[j, 21] = -1.0
+        parts = _all_gather_rows(self.dist, mine)
+        for j, k in enumerate(ids):
+            row = parts[j % self.world][j]
+            if row[21] > 0:
+                self.boxes[k] = (row[0:3].copy(), row[3:12].reshape(3, 3).copy(), row[12:15].copy(), row[15:18].copy(), row[18:21].copy())
+            elif row[21] < 0 and k not in self.failed:
+                self.failed[k] = RuntimeError(f'the box fit of instance {k} failed on rank {j % self.world}')
+        self.prof['exchange'] += time.perf_counter() - t0
 
     def box(self, i):
         """(center, R, extent, aabb_lo, aabb_hi) of instance i, refitted only after its membership changed."""
         i = int(i)
+        if i in self.failed:
+            raise self.failed[i]
         if i not in self.boxes:
-            t0 = time.perf_counter()
-            c, R, e = self.box_fn(self.pts[self.members[i]])
-            self.prof['fit'] += time.perf_counter() - t0; self.prof['nfit'] += 1
-            corners = obb_corners(c, R, e)
-            pad = 1e-9 * (np.abs(corners).max() + np.abs(e).max() + 1.0)       # the in-box test rounds; never prune a touching pair
-            self.boxes[i] = (c, R, e, corners.min(0) - pad, corners.max(0) + pad)
+            self.boxes[i] = self._fit(i)
         return self.boxes[i]
 
     def absorb(self, dst, src):
@@ -150,43 +315,41 @@ class _MergeState:
         dst, src = int(dst), int(src)
         t0 = time.perf_counter()
         moved = self.members.pop(src, None)
-        if moved is None or not len(moved):
+        if not moved:
             return
-        self.ids[moved] = dst
-        cur = self.members.get(dst)
-        self.members[dst] = np.sort(moved) if cur is None else np.sort(np.concatenate([cur, moved]))
-        self.boxes.pop(dst, None)
-        self.boxes.pop(src, None)
+        for part in moved:
+            self.ids[part] = dst
+        self.members.setdefault(dst, []).extend(moved)
+        self.counts[dst] = self.counts.get(dst, 0) + self.counts.pop(src, 0)
+        cs = self.cands.pop(src)
+        self.cands[dst] = np.sort(np.concatenate([self.cands[dst], cs])) if dst in self.cands else cs   # hull(A u B) has its vertices among both lists
+        self.boxes.pop(dst, None); self.boxes.pop(src, None)
+        self.failed.pop(dst, None); self.failed.pop(src, None)
         self.prof['absorb'] += time.perf_counter() - t0
 
     def shares_point(self, box1, others):
-        """For each box in `others`: does some cloud point lie in both it and box1?  One launch over the cloud."""
-        hits = np.zeros(len(others), bool)
+        """For each box in `others`: does some cloud point lie in both it and box1?  One launch over (this rank's share of) the cloud,
+        one all_reduce(MAX) of the answers when sharded."""
+        hits = np.zeros(len(others), np.uint8)
         t0 = time.perf_counter()
         for s in range(0, len(others), f3d.MAX_OBB - 1):
             part = [box1] + others[s:s + f3d.MAX_OBB - 1]
-            packed = _pack([(b[0], b[1], b[2]) for b in part])
-            if self.dev is None:
-                _, cooc = self.ctx.points_in_obb(self.pts, packed, want_bits=False, want_cooc=True)
-            else:
-                torch = self.torch
-                with torch.cuda.stream(self.stream):
-                    cd = torch.empty((len(part), len(part)), dtype=torch.uint8, device=self.device)
-                    self.ctx.points_in_obb_dev(self.dev.data_ptr(), f3d.F64, len(self.pts), packed, None, cd.data_ptr(),
-                                               self.stream.cuda_stream)
-                    self.stream.synchronize()
-                    cooc = cd.cpu().numpy().astype(bool)
+            cooc = self.cloud.cooccurrence(_pack([(b[0], b[1], b[2]) for b in part]))
             hits[s:s + len(part) - 1] = cooc[0, 1:]
+        if self.dist is not None:
+            t1 = time.perf_counter()
+            hits = sharding.sharded_cooccurrence(self.dist, hits)
+            self.prof['exchange'] += time.perf_counter() - t1
         self.prof['scan'] += time.perf_counter() - t0; self.prof['nscan'] += 1
-        return hits
+        return hits.astype(bool)
 
 
-def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, info_sem, box_fn=obb_from_points, state=None):
+def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, info_sem, box_fn=None, state=None):
     """Ids (list indices) whose box shares a cloud point with the box of id1 (reference :68-91).
 
     Same decisions as the reference, fewer scans: a partner whose box's axis-aligned bounds do not touch those of
     id1's box cannot share a point with it, so only the touching partners are tested on the GPU (exact pruning)."""
-    st = state if state is not None else _MergeState(pcd_points, id_info_per_point, box_fn)
+    st = state if state is not None else _MergeState(pcd_points, id_info_per_point, box_fn or obb_from_points)
     if st.count(id1) < 4:
         return []
     box1 = st.box(id1)
@@ -205,13 +368,17 @@ def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, 
     return [c for c, h in zip(cand, hit) if h]
 
 
-def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=obb_from_points):
-    """Merge same-parent instances whose boxes share a point; writes final_info.json and ids.npy (reference :103-137)."""
+def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=None, dist=None, backend=None):
+    """Merge same-parent instances whose boxes share a point; writes final_info.json and ids.npy (reference :103-137).
+    ``dist``: an initialised ``torch.distributed`` module -- every rank calls merge_bb with the same arguments, scans its share of
+    the points and gets the same result (rank 0 writes the files).  ``backend``: the object that groups and scans the cloud
+    (default: the HIP library; the CPU tests of the sharded control flow inject a NumPy one)."""
+    box_fn = box_fn or obb_from_points
     n0 = len(info_sem)
     pts = np.ascontiguousarray(np.asarray(pcd.points if hasattr(pcd, 'points') else pcd), dtype=np.float64)
     t0 = time.perf_counter()
     id_list = [info_sem[i]["id"] for i in range(len(info_sem))]
-    st = _MergeState(pts, id_info_per_point, box_fn)
+    st = _MergeState(pts, id_info_per_point, box_fn, dist, backend)
     for id1 in range(1, len(id_list)):
         hits = check_intersection_open3d(id1, id_list, id_info_per_point, pts, pcd, info_sem, box_fn, st)
         if hits:
@@ -229,7 +396,7 @@ def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=obb_from_points)
     print(f'Time taken for merging {n0} to {len(info_sem)} Bounding boxes = {time.perf_counter() - t0} seconds')
     if os.environ.get('F3D_MERGE_PROFILE'):
         print('merge_bb breakdown [s]: ' + ', '.join(f'{k}={v:.3f}' if isinstance(v, float) else f'{k}={v}' for k, v in st.prof.items()))
-    if dir_name is not None:
+    if dir_name is not None and (dist is None or dist.get_rank() == 0):
         out = Path(dir_name) / "panoptic_segmentation"
         out.mkdir(parents=True, exist_ok=True)
         with open(out / "final_info.json", 'w') as fp:

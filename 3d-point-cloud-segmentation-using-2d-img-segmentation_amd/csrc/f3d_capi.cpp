@@ -23,7 +23,8 @@ static_assert(offsetof(f3d_view, img_h) == offsetof(f3d_view, cull_n32) + 23 * 4
 namespace {
 
 enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_SORT_PERM, SLOT_SORT_SCRATCH,
-       SLOT_TILED_MASKS, SLOT_TODO, SLOT_GRAPH, SLOT_GRAPH_BBOX, SLOT_PATCH, SLOT_COUNT };
+       SLOT_TILED_MASKS, SLOT_TODO, SLOT_GRAPH, SLOT_GRAPH_BBOX, SLOT_PATCH,
+       SLOT_GRP_ORDER, SLOT_GRP_KEYS, SLOT_GRP_STARTS, SLOT_GRP_SCRATCH, SLOT_OBB_TABLE, SLOT_OBB_FACETS, SLOT_OBB_CAND, SLOT_COUNT };
 
 thread_local char g_create_err[512] = "";
 
@@ -49,6 +50,9 @@ struct f3d_ctx {
     int64_t graph_n;
     double graph_r2;
     const void* graph_xyz;
+    // instance grouping of the last f3d_group_by_id call (host-pointer sequence group -> extremes -> hull filter)
+    int64_t grp_n, grp_nids;
+    int grp_dtype;
 };
 
 namespace {
@@ -211,7 +215,7 @@ f3d_ctx* f3d_ctx_create(int device) {
     }
     if (device < 0 || device >= count) { fail(nullptr, F3D_ERR_INVALID, "device %d out of range [0,%d)", device, count); return nullptr; }
     f3d_ctx* ctx = (f3d_ctx*)calloc(1, sizeof(f3d_ctx));
-    if (ctx) ctx->graph_n = -1;
+    if (ctx) { ctx->graph_n = -1; ctx->grp_n = -1; }
     if (!ctx) { fail(nullptr, F3D_ERR_NOMEM, "out of host memory"); return nullptr; }
     ctx->device = device;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -1096,6 +1100,111 @@ int f3d_radius_graph_fill(f3d_ctx* ctx, int64_t n, int32_t* nbrs) {
     if ((rc = ensure(ctx, SLOT_MASKS, (size_t)nnz * 4, &dnb))) return rc;
     if ((rc = f3d_radius_graph_fill_dev(ctx, n, doffs, (int32_t*)dnb, s))) return rc;
     F3D_HIP(ctx, hipMemcpyAsync(nbrs, dnb, (size_t)nnz * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge_bb support: grouping by instance id, hull candidates of every instance
+// ---------------------------------------------------------------------------------------------
+int f3d_group_by_id_dev(f3d_ctx* ctx, const int64_t* ids, int64_t n, int64_t nids, int32_t* order, uint32_t* sorted_ids, int64_t* starts,
+                        void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || n > 0x7fffffffLL || nids < 0 || nids >= 0x7fffffffLL || !starts || (n > 0 && (!ids || !order || !sorted_ids)))
+        return fail(ctx, F3D_ERR_INVALID, "group_by_id: bad arguments (n, nids < 2^31)");
+    void* scratch;
+    if ((rc = ensure(ctx, SLOT_GRP_SCRATCH, f3d_group_scratch_bytes(n, nids), &scratch))) return rc;
+    F3D_HIP(ctx, f3d_launch_group_by_id(ids, n, nids, order, sorted_ids, starts, scratch, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_obb_extremes_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const int32_t* order, const uint32_t* sorted_ids,
+                         int64_t nids, int32_t* extremes, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || nids < 0 || (nids > 0 && !extremes) || (n > 0 && (!xyz || !order || !sorted_ids)))
+        return fail(ctx, F3D_ERR_INVALID, "obb_extremes: bad arguments");
+    void* table;
+    if ((rc = ensure(ctx, SLOT_OBB_TABLE, (size_t)nids * F3D_OBB_NDIR * 8, &table))) return rc;
+    F3D_HIP(ctx, f3d_launch_obb_extremes(xyz, dtype, n, order, sorted_ids, nids, (unsigned long long*)table, extremes, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_obb_hull_filter_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const int32_t* order, const uint32_t* sorted_ids,
+                            const int64_t* starts, int64_t nids, const int32_t* facet_start, const double* facets, const double* margin,
+                            int32_t* cand, int32_t* cand_count, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || nids < 0 || (nids > 0 && (!facet_start || !margin || !cand_count || !starts)) || (n > 0 && (!xyz || !order || !sorted_ids || !cand)))
+        return fail(ctx, F3D_ERR_INVALID, "obb_hull_filter: bad arguments");
+    F3D_HIP(ctx, f3d_launch_obb_hull_filter(xyz, dtype, n, order, sorted_ids, starts, nids, facet_start, facets, margin, cand, cand_count,
+                                            pick(ctx, stream)));
+    return F3D_OK;
+}
+
+// host-pointer sequence; the grouping (and, from the extremes call on, the cloud) stays in the context between the calls
+int f3d_group_by_id(f3d_ctx* ctx, const int64_t* ids, int64_t n, int64_t nids, int32_t* order, int64_t* starts) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || nids < 0 || !starts || (n > 0 && (!ids || !order))) return fail(ctx, F3D_ERR_INVALID, "group_by_id: bad arguments");
+    ctx->grp_n = -1;
+    void *dids, *dorder, *dkeys, *dstarts;
+    if ((rc = ensure(ctx, SLOT_OUT0, (size_t)n * 8, &dids)) || (rc = ensure(ctx, SLOT_GRP_ORDER, (size_t)n * 4, &dorder)) ||
+        (rc = ensure(ctx, SLOT_GRP_KEYS, (size_t)n * 4, &dkeys)) || (rc = ensure(ctx, SLOT_GRP_STARTS, (size_t)(nids + 2) * 8, &dstarts)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    if (n) F3D_HIP(ctx, hipMemcpyAsync(dids, ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_group_by_id_dev(ctx, (const int64_t*)dids, n, nids, (int32_t*)dorder, (uint32_t*)dkeys, (int64_t*)dstarts, s))) return rc;
+    if (n) F3D_HIP(ctx, hipMemcpyAsync(order, dorder, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipMemcpyAsync(starts, dstarts, (size_t)(nids + 2) * 8, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    ctx->grp_n = n; ctx->grp_nids = nids;
+    return F3D_OK;
+}
+
+int f3d_obb_extremes(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, int32_t* extremes) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n != ctx->grp_n || n < 0) return fail(ctx, F3D_ERR_INVALID, "obb_extremes: call f3d_group_by_id for this cloud first");
+    const int64_t nids = ctx->grp_nids;
+    if ((n > 0 && !xyz) || (nids > 0 && !extremes)) return fail(ctx, F3D_ERR_INVALID, "obb_extremes: bad arguments");
+    void *dxyz, *dext;
+    if ((rc = ensure(ctx, SLOT_XYZ, xyz_bytes(dtype, n), &dxyz)) || (rc = ensure(ctx, SLOT_OBB_CAND, (size_t)(n > nids * F3D_OBB_NDIR ? n : nids * F3D_OBB_NDIR) * 4 + (size_t)nids * 4, &dext)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    if (n) F3D_HIP(ctx, hipMemcpyAsync(dxyz, xyz, xyz_bytes(dtype, n), hipMemcpyHostToDevice, s));
+    if ((rc = f3d_obb_extremes_dev(ctx, dxyz, dtype, n, (const int32_t*)ctx->slot[SLOT_GRP_ORDER], (const uint32_t*)ctx->slot[SLOT_GRP_KEYS], nids,
+                                   (int32_t*)dext, s))) return rc;
+    if (nids) F3D_HIP(ctx, hipMemcpyAsync(extremes, dext, (size_t)nids * F3D_OBB_NDIR * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    ctx->grp_dtype = dtype;
+    return F3D_OK;
+}
+
+int f3d_obb_hull_filter(f3d_ctx* ctx, int64_t n, const int32_t* facet_start, const double* facets, const double* margin, int32_t* cand,
+                        int32_t* cand_count) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n != ctx->grp_n || n < 0) return fail(ctx, F3D_ERR_INVALID, "obb_hull_filter: call f3d_group_by_id and f3d_obb_extremes for this cloud first");
+    const int64_t nids = ctx->grp_nids;
+    if (nids > 0 && (!facet_start || !margin || !cand_count)) return fail(ctx, F3D_ERR_INVALID, "obb_hull_filter: bad arguments");
+    if (nids == 0) return F3D_OK;
+    const int64_t nf = facet_start[nids];
+    if (nf < 0 || (nf > 0 && !facets) || (n > 0 && !cand)) return fail(ctx, F3D_ERR_INVALID, "obb_hull_filter: bad facet table");
+    void *dfac, *dcand;
+    const size_t fbytes = (size_t)(nids + 1) * 4, ebytes = (size_t)nf * 32, mbytes = (size_t)nids * 8;
+    if ((rc = ensure(ctx, SLOT_OBB_FACETS, ((fbytes + 7) & ~(size_t)7) + ebytes + mbytes + 64, &dfac)) ||
+        (rc = ensure(ctx, SLOT_OBB_CAND, (size_t)(n > nids * F3D_OBB_NDIR ? n : nids * F3D_OBB_NDIR) * 4 + (size_t)nids * 4, &dcand)))
+        return rc;
+    char* base = (char*)dfac;
+    int32_t* dfs = (int32_t*)base;
+    double* deq = (double*)(base + ((fbytes + 7) & ~(size_t)7));
+    double* dmg = deq + 4 * (size_t)nf;
+    int32_t* dcnt = (int32_t*)((char*)dcand + (size_t)(n > nids * F3D_OBB_NDIR ? n : nids * F3D_OBB_NDIR) * 4);
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dfs, facet_start, fbytes, hipMemcpyHostToDevice, s));
+    if (nf) F3D_HIP(ctx, hipMemcpyAsync(deq, facets, ebytes, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dmg, margin, mbytes, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_obb_hull_filter_dev(ctx, ctx->slot[SLOT_XYZ], (f3d_dtype)ctx->grp_dtype, n, (const int32_t*)ctx->slot[SLOT_GRP_ORDER],
+                                      (const uint32_t*)ctx->slot[SLOT_GRP_KEYS], (const int64_t*)ctx->slot[SLOT_GRP_STARTS], nids, dfs, deq, dmg,
+                                      (int32_t*)dcand, dcnt, s))) return rc;
+    if (n) F3D_HIP(ctx, hipMemcpyAsync(cand, dcand, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipMemcpyAsync(cand_count, dcnt, (size_t)nids * 4, hipMemcpyDeviceToHost, s));
     F3D_HIP(ctx, hipStreamSynchronize(s));
     return F3D_OK;
 }

@@ -123,3 +123,14 @@ hipError_t f3d_launch_sem_to_mask(const float* sem, int c, int64_t hw, float con
 hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, uint32_t* bits,
                                     uint8_t* cooc, hipStream_t s);
 hipError_t f3d_launch_relabel(int64_t* ids, int64_t n, int64_t from, int64_t to, unsigned long long* count, hipStream_t s);
+
+// merge_bb support (f3d_obb.hip): grouping of the points by instance id, extreme members along 26 directions, inner-hull filter
+#define F3D_OBB_NDIR 26
+size_t f3d_group_scratch_bytes(int64_t n, int64_t nids);
+hipError_t f3d_launch_group_by_id(const int64_t* ids, int64_t n, int64_t nids, int32_t* order, uint32_t* sorted_keys, int64_t* starts,
+                                  void* scratch, hipStream_t s);
+hipError_t f3d_launch_obb_extremes(const void* xyz, int dtype, int64_t n, const int32_t* order, const uint32_t* sorted_keys, int64_t nseg,
+                                   unsigned long long* table, int32_t* extremes, hipStream_t s);
+hipError_t f3d_launch_obb_hull_filter(const void* xyz, int dtype, int64_t n, const int32_t* order, const uint32_t* sorted_keys,
+                                      const int64_t* starts, int64_t nseg, const int32_t* fstart, const double* facets, const double* margin,
+                                      int32_t* cand, int32_t* cand_count, hipStream_t s);

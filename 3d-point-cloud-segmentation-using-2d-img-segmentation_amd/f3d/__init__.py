@@ -94,6 +94,12 @@ def library():
         'f3d_sem_logits_to_mask_dev': (i32, [vp, vp, i32, i64, flt, i32, vp, vp]),
         'f3d_points_in_obb': (i32, [vp, vp, i32, i64, vp, i32, vp, vp]),
         'f3d_points_in_obb_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, vp, vp]),
+        'f3d_group_by_id': (i32, [vp, vp, i64, i64, vp, vp]),
+        'f3d_obb_extremes': (i32, [vp, vp, i32, i64, vp]),
+        'f3d_obb_hull_filter': (i32, [vp, i64, vp, vp, vp, vp, vp]),
+        'f3d_group_by_id_dev': (i32, [vp, vp, i64, i64, vp, vp, vp, vp]),
+        'f3d_obb_extremes_dev': (i32, [vp, vp, i32, i64, vp, vp, i64, vp, vp]),
+        'f3d_obb_hull_filter_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
         'f3d_relabel': (i32, [vp, vp, i64, i64, i64, vp]),
         'f3d_relabel_dev': (i32, [vp, vp, i64, i64, i64, vp, vp]),
         'f3d_ray_x_lines': (i32, [vp, vp, vp, vp, vp, i64, vp, vp]),
@@ -356,6 +362,39 @@ class Context:
             inside = np.unpackbits(bits.view(np.uint8), axis=1, bitorder='little')[:, :B].astype(bool)
         return inside, (None if cooc is None else cooc.astype(bool))
 
+    # ---- per-instance point lists and hull candidates (merge_bb's box fits); host-pointer sequence, state kept in the context
+    def group_by_id(self, ids, nids):
+        """order int32 [n] (members of id 0, 1, ... in ascending point index; ids outside [0, nids) last), starts int64 [nids + 2]."""
+        i = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        order = np.empty(len(i), np.int32)
+        starts = np.empty(int(nids) + 2, np.int64)
+        self._check(self._lib.f3d_group_by_id(self._h, _ptr(i), len(i), int(nids), _ptr(order), _ptr(starts)))
+        self._grp = (len(i), int(nids))
+        return order, starts
+
+    def obb_extremes(self, points):
+        """int32 [nids, 26]: per id the member extreme along +-x, +-y, +-z and the face / body diagonals (-1: no members).
+        Follows group_by_id of the same cloud."""
+        p, dt = _xyz(points)
+        n, nids = self._grp
+        out = np.empty((nids, 26), np.int32)
+        self._check(self._lib.f3d_obb_extremes(self._h, _ptr(p), dt, len(p), _ptr(out)))
+        return out
+
+    def obb_hull_filter(self, facet_start, facets, margin):
+        """Members not strictly inside their id's polytope: (cand int32 [n] grouped like `order`, cand_count int32 [nids]).
+        Follows group_by_id and obb_extremes of the same cloud."""
+        n, nids = self._grp
+        fs = np.ascontiguousarray(facet_start, dtype=np.int32)
+        eq = np.ascontiguousarray(facets, dtype=np.float64).reshape(-1, 4)
+        mg = np.ascontiguousarray(margin, dtype=np.float64)
+        if len(fs) != nids + 1 or len(mg) != nids or fs[-1] != len(eq):
+            raise ValueError('facet_start must have nids + 1 entries ending at len(facets); margin one entry per id')
+        cand = np.empty(n, np.int32)
+        cnt = np.empty(nids, np.int32)
+        self._check(self._lib.f3d_obb_hull_filter(self._h, n, _ptr(fs), _ptr(eq), _ptr(mg), _ptr(cand), _ptr(cnt)))
+        return cand, cnt
+
     def relabel(self, ids, from_id, to_id):
         if ids.dtype != np.int64 or not ids.flags.c_contiguous:
             raise ValueError('ids must be a C-contiguous int64 array')
@@ -518,6 +557,17 @@ class Context:
     def points_in_obb_dev(self, xyz_ptr, dtype, n, boxes, bits_ptr, cooc_ptr, stream=None):
         b = _f64(boxes)
         self._check(self._lib.f3d_points_in_obb_dev(self._h, xyz_ptr, dtype, n, _ptr(b), len(b), bits_ptr, cooc_ptr, stream))
+
+    def group_by_id_dev(self, ids_ptr, n, nids, order_ptr, sorted_ids_ptr, starts_ptr, stream=None):
+        self._check(self._lib.f3d_group_by_id_dev(self._h, ids_ptr, n, int(nids), order_ptr, sorted_ids_ptr, starts_ptr, stream))
+
+    def obb_extremes_dev(self, xyz_ptr, dtype, n, order_ptr, sorted_ids_ptr, nids, extremes_ptr, stream=None):
+        self._check(self._lib.f3d_obb_extremes_dev(self._h, xyz_ptr, dtype, n, order_ptr, sorted_ids_ptr, int(nids), extremes_ptr, stream))
+
+    def obb_hull_filter_dev(self, xyz_ptr, dtype, n, order_ptr, sorted_ids_ptr, starts_ptr, nids, fstart_ptr, facets_ptr, margin_ptr,
+                            cand_ptr, cand_count_ptr, stream=None):
+        self._check(self._lib.f3d_obb_hull_filter_dev(self._h, xyz_ptr, dtype, n, order_ptr, sorted_ids_ptr, starts_ptr, int(nids), fstart_ptr,
+                                                      facets_ptr, margin_ptr, cand_ptr, cand_count_ptr, stream))
 
     def relabel_dev(self, ids_ptr, n, from_id, to_id, count_ptr=None, stream=None):
         self._check(self._lib.f3d_relabel_dev(self._h, ids_ptr, n, int(from_id), int(to_id), count_ptr, stream))

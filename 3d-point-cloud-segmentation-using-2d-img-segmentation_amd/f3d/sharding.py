@@ -63,3 +63,15 @@ def sharded_labels(dist, points, mask_shard, label_fn, gather=True):
         return local
     local_t = torch.as_tensor(np.ascontiguousarray(local)) if not isinstance(local, torch.Tensor) else local
     return gather_labels(dist, local_t, len(points))
+
+
+def sharded_cooccurrence(dist, local):
+    """The bbox-merge exchange step (SURVEY 8(e)): every rank has scanned ITS share of the points against the same boxes;
+    `local` (uint8 / bool array of any shape: a B x B co-occurrence matrix or one row of it) says which box pairs share a point
+    of that share.  One all_reduce(MAX) -- "some rank saw a common point" -- gives every rank the answer for the whole cloud."""
+    import torch
+    arr = np.ascontiguousarray(local, dtype=np.uint8)
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.from_numpy(arr.astype(np.int32)).to(dev)          # gloo has no MAX for uint8
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.cpu().numpy().astype(np.uint8)

@@ -253,6 +253,31 @@ int f3d_relabel(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
 int f3d_relabel_dev(f3d_ctx* ctx, int64_t* ids, int64_t n, int64_t from, int64_t to,
                     int64_t* count_dev, void* stream);
 
+/* ---- a10/a11: per-instance point lists and hull candidates for the oriented-box fits of merge_bb -------- */
+/* The reference builds points[ids == id] for every instance (merge_intersecting_bb.py:72-74,81-82,124-125; get3DSeg.py:434)
+ * and fits a box on it (Open3D: convex hull -> PCA of the hull vertices).
+ * f3d_group_by_id: stable grouping of the point indices by id.  order int32 [n] lists the members of id 0, then id 1, ...
+ * (ids outside [0, nids) last), each in ascending point index; starts int64 [nids + 2]: id k owns
+ * order[starts[k] .. starts[k + 1]), starts[nids + 1] = n.  sorted_ids (device variant) uint32 [n] = the id of every position.
+ * f3d_obb_extremes: extremes int32 [nids, 26] = for every id the member that is extreme along +-x, +-y, +-z and the 10 face /
+ * body diagonals (float32 dot products; -1 for an id without members).
+ * f3d_obb_hull_filter: with the facets (n . p + o <= 0 inside; double [F, 4], facet_start int32 [nids + 1] per id) of a convex
+ * polytope spanned by MEMBERS of the id (e.g. the hull of its <= 26 extremes), drops every member strictly inside it by more
+ * than margin[id]: such a point is interior to the hull of all members, so hull and box of the survivors are those of the
+ * whole instance.  cand int32 [n]: the survivors of id k at cand[starts[k] ..], cand_count[k] of them, in no particular order.
+ * The host-pointer variants form a sequence (group -> extremes -> hull_filter); the grouping and the cloud stay in the context. */
+int f3d_group_by_id(f3d_ctx* ctx, const int64_t* ids, int64_t n, int64_t nids, int32_t* order, int64_t* starts);
+int f3d_obb_extremes(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, int32_t* extremes);
+int f3d_obb_hull_filter(f3d_ctx* ctx, int64_t n, const int32_t* facet_start, const double* facets, const double* margin,
+                        int32_t* cand, int32_t* cand_count);
+int f3d_group_by_id_dev(f3d_ctx* ctx, const int64_t* ids, int64_t n, int64_t nids, int32_t* order, uint32_t* sorted_ids,
+                        int64_t* starts, void* stream);
+int f3d_obb_extremes_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const int32_t* order,
+                         const uint32_t* sorted_ids, int64_t nids, int32_t* extremes, void* stream);
+int f3d_obb_hull_filter_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const int32_t* order,
+                            const uint32_t* sorted_ids, const int64_t* starts, int64_t nids, const int32_t* facet_start,
+                            const double* facets, const double* margin, int32_t* cand, int32_t* cand_count, void* stream);
+
 /* ---- a12 / (f)#4: the other primitives of Fusion3DSeg/intersections.py (host pointers) ---- */
 /* ray_x_lines (:6-38): points [n,3], within uint8 [n] */
 int f3d_ray_x_lines(f3d_ctx* ctx, const double origin[3], const double direction[3], const double* starts,

@@ -243,6 +243,110 @@ def test_merge_bb_randomised_against_oracle(seed, nblobs, spread):
             assert np.allclose(g['bbox'], w['bbox'])
 
 
+def _c5_blobs(B, n, seed=3456):
+    """The C5 merge recipe of SURVEY 8(d): n points in B Gaussian blobs (sigma 0.15 m, centres uniform in the cloud box), parent = id mod 8."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform([-5, -5, 0], [5, 5, 3], (B, 3))
+    ids = rng.integers(1, B, n).astype(np.int64)
+    pts = centres[ids] + rng.normal(size=(n, 3)) * 0.15
+    info = [{'id': k, 'category_id': 86, 'parent_id': k % 8, 'area': int((ids == k).sum())} for k in range(B)]
+    return pts, ids, info
+
+
+def test_group_by_id_extremes_and_hull_filter_kernels():
+    """The GPU grouping equals np.nonzero(ids == k) for every id; the reported extremes are members with the maximal dot product;
+    the survivors of the hull filter contain every vertex of the full hull, so the box fitted on them is the box of all members."""
+    from scipy.spatial import ConvexHull
+    import f3d
+    ctx = f3d.default_context()
+    rng = np.random.default_rng(17)
+    nids = 37
+    n = 60_000
+    ids = rng.integers(-2, nids + 3, n).astype(np.int64)               # some ids outside [0, nids)
+    ids[ids == 5] = 6                                                  # an id without members
+    centres = rng.uniform(-4, 4, (nids + 3, 3))
+    pts = centres[np.clip(ids, 0, nids + 2)] + rng.normal(size=(n, 3)) * [0.4, 0.2, 0.1]
+    order, starts = ctx.group_by_id(ids, nids)
+    assert starts[0] == 0 and starts[nids + 1] == n and starts[5] == starts[6]
+    for k in range(nids):
+        assert np.array_equal(order[starts[k]:starts[k + 1]], np.nonzero(ids == k)[0]), k
+    assert set(order[starts[nids]:].tolist()) == set(np.nonzero((ids < 0) | (ids >= nids))[0].tolist())
+    ext = ctx.obb_extremes(pts)
+    assert (ext[5] == -1).all()
+    p32 = pts.astype(np.float32)
+    x, y, z = p32[:, 0], p32[:, 1], p32[:, 2]
+    dots = np.stack([x, y, z, x + y, x - y, x + z, x - z, y + z, y - z, (x + y) + z, (x + y) - z, (x - y) + z, (x - y) - z])
+    for k in (0, 7, 36):
+        mem = np.nonzero(ids == k)[0]
+        for d in range(13):
+            assert ids[ext[k, 2 * d]] == k and dots[d, ext[k, 2 * d]] == dots[d, mem].max()
+            assert ids[ext[k, 2 * d + 1]] == k and dots[d, ext[k, 2 * d + 1]] == dots[d, mem].min()
+    fstart, eqs, margin = np.zeros(nids + 1, np.int32), [], np.zeros(nids)
+    nf = np.zeros(nids, np.int64)
+    for k in range(nids):
+        e = np.unique(ext[k][ext[k] >= 0])
+        if len(e) >= 4 and k % 5:                                      # every fifth id gets no facets: nothing may be dropped there
+            eq = ConvexHull(pts[e]).equations
+            eqs.append(eq); nf[k] = len(eq); margin[k] = 1e-9 * (np.abs(pts[e]).max() + 1)
+    fstart[1:] = np.cumsum(nf)
+    cand, cnt = ctx.obb_hull_filter(fstart, np.concatenate(eqs), margin)
+    dropped = 0
+    for k in range(nids):
+        mem = np.nonzero(ids == k)[0]
+        c = np.sort(cand[starts[k]:starts[k] + cnt[k]])
+        assert set(c.tolist()) <= set(mem.tolist())
+        if nf[k] == 0:
+            assert np.array_equal(c, mem)
+            continue
+        hull_vertices = mem[ConvexHull(pts[mem]).vertices]
+        assert set(hull_vertices.tolist()) <= set(c.tolist()), k
+        for a, b in zip(O.obb_from_points(pts[c]), O.obb_from_points(pts[mem])):
+            assert np.array_equal(a, b)                                # bit for bit the same box
+        dropped += len(mem) - len(c)
+    assert dropped > 0.8 * (ids >= 0).sum() * 0.7                      # the filter really removes most members
+
+
+def test_merge_bb_c5_recipe_against_oracle_and_prefilter_off():
+    """merge_bb on the C5 recipe (Gaussian blobs, parent = id mod 8): equal to the oracle's literal control flow at a size the
+    oracle can afford, and -- 2M points, 512 instances -- equal with the hull prefilter switched off (boxes bit for bit)."""
+    import Fusion3DSeg.merge_intersecting_bb as M
+    pts, ids, info = _c5_blobs(160, 40_000)
+    want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
+    got_info, got_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts, box_fn=O.obb_from_points)
+    assert np.array_equal(got_ids, want_ids) and len(got_info) < len(info)
+    assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info]
+    for g, w in zip(got_info, want_info):
+        assert ('bbox' in g) == ('bbox' in w) and ('bbox' not in g or np.array_equal(np.array(g['bbox']), np.array(w['bbox'])))
+    pts, ids, info = _c5_blobs(512, 2_000_000)
+    a_info, a_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts)
+    keep = M._MergeState.PREFILTER_MIN
+    try:
+        M._MergeState.PREFILTER_MIN = 1 << 60
+        b_info, b_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts)
+    finally:
+        M._MergeState.PREFILTER_MIN = keep
+    assert np.array_equal(a_ids, b_ids) and json.dumps(a_info) == json.dumps(b_info) and len(a_info) < len(info)
+
+
+def test_config_c5_merge_50m_points_4096_instances():
+    """C5's merge leg at full size (BASELINE.json config 5): 50M points, 4096 instances.  The oracle cannot afford this size; checked
+    are the count two earlier generations of this code produced for the same seeded scene (profiles/r02_merge_c5_breakdown.md) and
+    that instances really disappear into others.  (No "same parent" property holds: the reference looks parents up by LIST INDEX
+    after entries have been deleted -- quirk Q6/Q7 -- which the drop-in reproduces.)"""
+    import time
+    from Fusion3DSeg.merge_intersecting_bb import merge_bb
+    pts, ids, info = _c5_blobs(4096, 50_000_000)
+    before = ids.copy()
+    t0 = time.perf_counter()
+    out_info, out_ids = merge_bb(None, info, ids, pts)
+    dt = time.perf_counter() - t0
+    assert len(out_info) == 3964
+    moved = out_ids != before
+    assert moved.any() and len(np.unique(out_ids)) < len(np.unique(before))
+    assert sum(1 for d in out_info[1:] if 'bbox' in d) > 3900
+    print(f'C5 merge_bb: {dt:.2f} s')
+
+
 def _info_rows(info):
     return np.array([[d['id'], int(d['isthing']), d['category_id'], d['area']] for d in info], np.int64).reshape(-1, 4)
 

@@ -57,3 +57,87 @@ def test_two_rank_sharded_labels_equal_single_process(tmp_path):
                                  133, 0.5, [86, 114, 115])
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f'labels_{r}.npy'), want)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# bbox merge: scans sharded by point range, one all_reduce(MAX) per co-occurrence answer, initial
+# box fits dealt out by instance and all-gathered, control flow replicated on every rank
+# ------------------------------------------------------------------------------------------------------------
+class NumpyCloud:
+    """Stand-in for the HIP cloud on a machine without a GPU: same interface, the oracle's in-box test, this rank's points only."""
+
+    def __init__(self, pts, share):
+        self.pts, (self.lo, self.hi) = pts, share
+
+    def group(self, ids, nids):
+        order = np.argsort(ids, kind='stable').astype(np.int32)
+        return order, np.searchsorted(ids[order], np.arange(nids + 2)).astype(np.int64)
+
+    def cooccurrence(self, packed):
+        mine = self.pts[self.lo:self.hi]
+        m = np.stack([O.points_in_obb(mine, b[0:3], b[3:12].reshape(3, 3), b[12:15]) for b in packed]).astype(np.float32)
+        return ((m @ m.T) > 0).astype(np.uint8)
+
+
+def _merge_scene(seed=9):
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(0, 3.0, (16, 3))
+    pts = np.vstack([c + rng.normal(size=(250, 3)) * [0.5, 0.3, 0.1] for c in centres])
+    ids = np.repeat(np.arange(16), 250).astype(np.int64)
+    perm = rng.permutation(len(pts))                                   # members of an instance spread over both shards
+    pts, ids = pts[perm], ids[perm]
+    ids[ids == 15] = 14                                                # one instance with no points at all
+    info = [{'id': k, 'category_id': 86 + (k % 3), 'parent_id': k % 2, 'area': int((ids == k).sum())} for k in range(16)]
+    return pts, ids, info
+
+
+def _merge_worker(rank, world, port, out_dir):
+    import copy
+    import json
+    from Fusion3DSeg.merge_intersecting_bb import merge_bb
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        pts, ids, info = _merge_scene()
+        out_info, out_ids = merge_bb(out_dir, copy.deepcopy(info), ids, pts, box_fn=O.obb_from_points, dist=dist, backend=NumpyCloud)
+        np.save(os.path.join(out_dir, f'ids_{rank}.npy'), out_ids)
+        with open(os.path.join(out_dir, f'info_{rank}.json'), 'w') as fp:
+            json.dump(out_info, fp)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_cooccurrence_is_an_or_over_ranks():
+    class FakeDist:                                                    # one "rank": the reduction is the identity, the dtype contract holds
+        ReduceOp = dist.ReduceOp
+
+        @staticmethod
+        def get_backend():
+            return 'gloo'
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            return None
+    got = sharding.sharded_cooccurrence(FakeDist, np.array([[1, 0], [0, 1]], bool))
+    assert got.dtype == np.uint8 and got.tolist() == [[1, 0], [0, 1]]
+
+
+def test_two_rank_sharded_merge_bb_equals_single_process(tmp_path):
+    """world size 2, gloo: every rank scans half of the points; ids, areas, surviving entries and boxes equal the oracle's
+    single-process literal restatement (reference merge_intersecting_bb.py:103-137); rank 0 alone writes the files."""
+    import copy
+    import json
+    world = 2
+    mp.spawn(_merge_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pts, ids, info = _merge_scene()
+    want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
+    assert len(want_info) < len(info)                                  # something merged
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f'ids_{r}.npy'), want_ids), r
+        got = json.loads((tmp_path / f'info_{r}.json').read_text())
+        assert [d['id'] for d in got] == [d['id'] for d in want_info] and [d['area'] for d in got] == [d['area'] for d in want_info]
+        for g, w in zip(got, want_info):
+            assert ('bbox' in g) == ('bbox' in w)
+            if 'bbox' in w:
+                assert np.array_equal(np.array(g['bbox']), np.array(w['bbox']))
+    assert np.array_equal(np.load(tmp_path / 'panoptic_segmentation' / 'ids.npy'), want_ids)
