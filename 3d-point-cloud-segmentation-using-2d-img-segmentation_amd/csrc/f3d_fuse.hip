@@ -117,6 +117,7 @@ __device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W) {        
 #define F3D_CODE_NONE 0u
 #define F3D_CODE_BAD 1u
 #define F3D_CODE_OTHER 2u
+#define F3D_PACKED_SMALL_WORDS 12             // packed 8-bit bins: alphabets up to 48 codes get the medium-LDS instance
 #define F3D_BIN32_MAX_CODES 12               // alphabets up to this many codes vote into dword bins (12 KiB of LDS per 256 points: 4 blocks per CU)
 
 // One view of the coded masks: (ceil(H/8) + 2) x (ceil(W/8) + 2) tiles of 8x8 pixels (64 B each): the image plus a one-tile border of
@@ -606,7 +607,7 @@ __device__ __forceinline__ float wave_reduce(float v) {
 #ifndef F3D_FUSE_WAVES
 #define F3D_FUSE_WAVES 3                 // waves per SIMD the register allocation of k_fuse must allow (4 spills: measured slower)
 #endif
-template <typename T, bool WRITE_VOTES, bool BIN32, bool WRAP>
+template <typename T, int PPL, bool WRITE_VOTES, bool BIN32, bool WRAP>
 __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
                                                      const uint8_t* __restrict__ cmasks, int H, int W,
@@ -627,7 +628,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
     const uint8_t* inv = lut + 256;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
-    constexpr int TILE = F3D_BLOCK * 2;
+    constexpr int TILE = F3D_BLOCK * PPL;                                 // PPL = 2 points per lane; 1 for alphabets whose histograms would
+                                                                          // otherwise leave room for a single block per CU (the second slot idles)
     const int npts = (int)n;                                              // n < 2^31 - TILE (checked by the launcher): 32-bit indices
     const int ntiles = (int)((n + TILE - 1) / TILE);
     const unsigned plane = (unsigned)f3d_coded_plane(H, W);               // bytes per view of the coded masks (V * plane < 2^32: launcher)
@@ -657,11 +659,11 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     const int tiles_per_xcd = (ntiles + 7) / 8;
     const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = gridDim.x >> 3;
     uint32_t* const hcol0 = hist + tid;
-    uint32_t* const hcol1 = hist + hdw * F3D_BLOCK + tid;
+    uint32_t* const hcol1 = PPL == 2 ? hist + hdw * F3D_BLOCK + tid : hcol0;
     for (int j = bx; j < tiles_per_xcd; j += gx) {
         const int tile = xcd * tiles_per_xcd + j;
         if (tile >= ntiles) break;
-        const int i0 = tile * TILE + (tid >> 6) * 128 + lane;             // this lane's first point; its second is i0 + 64
+        const int i0 = tile * TILE + (tid >> 6) * (64 * PPL) + lane;      // this lane's first point; its second is i0 + 64
         bool live[2], act[2], defer[2];
         int orig[2];
         f32x2 DX, DY, DZ;                                                  // offsets of the lane's two points from the box centre
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int i = i0 + 64 * q;
-                live[q] = i < npts;
+                live[q] = (q < PPL) & (i < npts);
                 orig[q] = live[q] ? (perm ? perm[i] : i) : i;                      // caller-order index of this point
                 p[q].x = p[q].y = p[q].z = 0.0;
                 if (live[q]) p[q] = load_point(xyz, (int64_t)(gather_xyz ? orig[q] : i));
@@ -700,13 +702,14 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             DY = (f32x2){(float)(p[0].y - (double)c1), (float)(p[1].y - (double)c1)};
             DZ = (f32x2){(float)(p[0].z - (double)c2), (float)(p[1].z - (double)c2)};
         }
-        for (int wd = 0; wd < hdw; ++wd) { hcol0[wd * F3D_BLOCK] = 0u; hcol1[wd * F3D_BLOCK] = 0u; }   // own columns only: no barrier
+        for (int wd = 0; wd < hdw; ++wd) { hcol0[wd * F3D_BLOCK] = 0u; if (PPL == 2) hcol1[wd * F3D_BLOCK] = 0u; }   // own columns only: no barrier
         unsigned nvalid[2] = {0u, 0u};
         unsigned pend[2] = {F3D_CODE_NONE, F3D_CODE_NONE};   // software-pipelined gathers: a code is voted one view (chunk) later
         unsigned ccode[2][F3D_CHUNK];
 #pragma unroll
         for (int k = 0; k < F3D_CHUNK; ++k) ccode[0][k] = ccode[1][k] = F3D_CODE_NONE;
         auto vote = [&](int q, unsigned b) {
+            if (q >= PPL) return;
             if (BIN32) vote_bin32(q ? hcol1 : hcol0, b);
             else vote_coded<WRAP>(nvalid[q], q ? hcol1 : hcol0, b);
         };
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     int fi0[2], fi1[2]; bool safe[2];
                     project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < PPL; ++q) {
                         const bool hit = safe[q] & act[q] & use[k];
                         defer[q] = defer[q] | (!safe[q] & act[q] & use[k]);
                         coff[q][k] = hit ? r.obase + rel_offset(fi0[q], fi1[q], c_row) : 0u;   // offset 0: a border tile, "no sample"
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) { vote(0, ccode[0][k]); vote(1, ccode[1][k]); }
 #pragma unroll
-                for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = cmasks[coff[0][k]]; ccode[1][k] = cmasks[coff[1][k]]; }
+                for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = cmasks[coff[0][k]]; if (PPL == 2) ccode[1][k] = cmasks[coff[1][k]]; }
             }
 #pragma unroll
             for (int k = 0; k < F3D_CHUNK; ++k) {
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     int fi0[2], fi1[2]; bool safe[2];
                     project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < PPL; ++q) {
                         const bool inside = act[q] & sure[q];
                         const bool hit = inside & safe[q] & ((unsigned)(fi0[q] + U8) < (unsigned)W) & ((unsigned)(fi1[q] + V8) < (unsigned)H);
                         defer[q] = defer[q] | (act[q] & maybe[q] & !sure[q]) | (inside & !safe[q]);
@@ -821,14 +824,14 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) defer[q] = defer[q] | (act[q] & maybe[q]);   // the box comes too close to this view's camera plane
+                    for (int q = 0; q < PPL; ++q) defer[q] = defer[q] | (act[q] & maybe[q]);   // the box comes too close to this view's camera plane
                 }
                 vote(0, pend[0]); vote(1, pend[1]);
-                pend[0] = cmasks[off[0]]; pend[1] = cmasks[off[1]];
+                pend[0] = cmasks[off[0]]; if (PPL == 2) pend[1] = cmasks[off[1]];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < PPL; ++q) {
             vote(q, pend[q]);
             uint32_t* hc = q ? hcol1 : hcol0;
             bool bad = false, trusted = true;
@@ -1093,8 +1096,8 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 #define F3D_FUSE_GRID (256 * 4 * 8)     // k_fuse: blocks per launch (multiple of 8; several rounds so that the tail stays short)
 #endif
 
-static size_t fuse_lds_bytes(int hist_dwords_per_point) {           // k_fuse: tables + 2 points per lane x histogram
-    return (64 * F3D_CULL_ROW + 128 + 2 * F3D_VHEAD * 64) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * 2 * F3D_BLOCK * sizeof(uint32_t);
+static size_t fuse_lds_bytes(int hist_dwords_per_point, int ppl) {   // k_fuse: tables + histogram of `ppl` points per lane
+    return (64 * F3D_CULL_ROW + 128 + 2 * F3D_VHEAD * 64) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
 }
 
 size_t f3d_fuse_lds_bytes(int mode, int nclasses) {                 // LDS of k_fuse_exact
@@ -1152,31 +1155,39 @@ template <typename T, bool V>
 static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* views_dev, int nviews, const uint8_t* masks, const uint8_t* cmasks,
                                 int h, int w, int nclasses, const f3d_filter_args& flt, double threshold, int64_t* classes, uint16_t* votes,
                                 int* err, const int32_t* perm, bool gather_xyz, unsigned int* todo_count, int32_t* todo,
-                                unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, int mode, int grid, hipStream_t s) {
+                                unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, int mode, int grid, int grid1, hipStream_t s) {
     const bool fast = cmasks != nullptr;                     // no coded masks (nclasses > F3D_CODE_MAX_NCLASSES): exact kernel only
     if (fast && (n > 0x7ffff000LL || (flt.nfilter > 0 && !flt.cls_dev) || (uint64_t)nviews * f3d_coded_plane(h, w) >= (1ull << 32)))
         return hipErrorInvalidValue;                         // 32-bit point indices and mask offsets; filter list in device memory
     const dim3 g(grid), b(F3D_BLOCK), ge(fast ? 512 : grid);
     const int words_max = (nclasses + 1 + 2 + 3) >> 2;      // every label 0..nclasses present, plus the codes "no sample" and "rejected"
-    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES), lds_full = fuse_lds_bytes(words_max);
+    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2), lds_full = fuse_lds_bytes(words_max, 1);
     const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses);
     if (lds_exact > 160 * 1024 || lds_full > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e;
     if (fast) {
         const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
-        auto ks = k_fuse<T, V, true, false>;                 // dword bins: at most F3D_BIN32_MAX_CODES codes
-        auto kf = wrap ? k_fuse<T, V, false, true> : k_fuse<T, V, false, false>;   // 8-bit bins, 4 per dword: any alphabet
+        auto ks = k_fuse<T, 2, V, true, false>;              // dword bins: at most F3D_BIN32_MAX_CODES codes
+        auto km2 = wrap ? k_fuse<T, 2, V, false, true> : k_fuse<T, 2, V, false, false>;   // 8-bit bins, 4 per dword, 2 points per lane
+        auto kf = wrap ? k_fuse<T, 1, V, false, true> : k_fuse<T, 1, V, false, false>;    // any alphabet: 1 point per lane (LDS)
         if ((e = raise_lds(ks, lds_small)) != hipSuccess || (e = raise_lds(kf, lds_full)) != hipSuccess) return e;
-        // two instances are enqueued; the code book on the device says which one runs, the other returns at once
+        // three instances are enqueued (dword bins for tiny alphabets; packed 8-bit bins with LDS for up to F3D_PACKED_SMALL_WORDS
+        // words, i.e. 48 codes; packed bins for any alphabet): LDS per block decides how many blocks a CU holds, and only the device
+        // knows how many labels the masks contain -- the code book says which instance runs, the others return at once
+        const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2);
         hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
                            classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES);
-        hipLaunchKernelGGL(kf, g, b, lds_full, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
-                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 256);
+        if (nclasses + 3 > F3D_BIN32_MAX_CODES)
+            hipLaunchKernelGGL(km2, g, b, lds_mid, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
+                               classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS);
+        if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS)
+            hipLaunchKernelGGL(kf, dim3(grid1), b, lds_full, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev,
+                               threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 256);
         // middle tier: the deferred points again, in float64; what it cannot prove either lands in the second list
         auto km = k_fuse_mid<T, V>;
-        const size_t lds_mid = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
-        if ((e = raise_lds(km, lds_mid)) != hipSuccess) return e;
-        hipLaunchKernelGGL(km, dim3(1024), b, lds_mid, s, (const T*)xyz, todo_count, todo, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
+        const size_t lds_tier2 = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
+        if ((e = raise_lds(km, lds_tier2)) != hipSuccess) return e;
+        hipLaunchKernelGGL(km, dim3(1024), b, lds_tier2, s, (const T*)xyz, todo_count, todo, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
                            flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo2_count, todo2, cb);
     }
     if (mode == MODE_HIST8) {
@@ -1202,14 +1213,15 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     unsigned int* todo2_count = todo_count + 1;
     int32_t* todo2 = todo + n;
     const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);      // bins of the exact kernel; the fast one uses 8 bits
-    const int64_t ntiles = (n + F3D_BLOCK * 2 - 1) / (F3D_BLOCK * 2);          // k_fuse: 2 points per lane
-    int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID);
-    grid = (grid + 7) & ~7;                                  // the XCD-aware tile mapping needs a multiple of 8 blocks
+    const int64_t ntiles = (n + F3D_BLOCK * 2 - 1) / (F3D_BLOCK * 2);          // k_fuse: 2 points per lane ...
+    const int64_t ntiles1 = (n + F3D_BLOCK - 1) / F3D_BLOCK;                   // ... 1 in the any-alphabet instance
+    int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID), grid1 = (int)(ntiles1 < F3D_FUSE_GRID ? ntiles1 : F3D_FUSE_GRID);
+    grid = (grid + 7) & ~7; grid1 = (grid1 + 7) & ~7;        // the XCD-aware tile mapping needs a multiple of 8 blocks
     if (cmasks) {
         hipError_t e0 = hipMemsetAsync(todo_count, 0, 4 * sizeof(unsigned int), s);
         if (e0 != hipSuccess) return e0;
     }
-#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, mode, grid, s
+#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, mode, grid, grid1, s
     if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true>(F3D_ARGS) : launch_fuse_t<double, false>(F3D_ARGS);
     return votes ? launch_fuse_t<float, true>(F3D_ARGS) : launch_fuse_t<float, false>(F3D_ARGS);
 #undef F3D_ARGS

@@ -70,10 +70,14 @@ def masks(V, h, w, kind='block64', seed=9012):
     rng = np.random.default_rng(seed)
     if kind == 'iid':
         return rng.integers(0, 134, (V, h, w), dtype=np.uint8)
-    if kind != 'block64':
+    if kind == 'block64x40':                              # 40 labels: the packed-bin instance of the fused kernel
+        alphabet = np.arange(0, 133, 133 // 40, dtype=np.uint8)[:40]
+    elif kind == 'block64':
+        alphabet = ALPHABET
+    else:
         raise ValueError(kind)
     bh, bw = (h + 63) // 64, (w + 63) // 64
-    blocks = ALPHABET[rng.integers(0, len(ALPHABET), (V, bh, bw))]
+    blocks = alphabet[rng.integers(0, len(alphabet), (V, bh, bw))]
     return np.ascontiguousarray(np.repeat(np.repeat(blocks, 64, axis=1), 64, axis=2)[:, :h, :w])
 
 

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Headline benchmark: labelled points / second of the fused Fusion3DSeg hot path on MI355X.
 
-One step = one pass of the hot path over one batch: every point of the rank's cloud shard is
-projected into all V views, sampled, voted and segmented (f3d_project_vote_argmax_dev), with the
-inputs already resident in HBM.  Workload at N=1: BASELINE.json config C3 (10M points x 64 views,
-1024x1024 masks).  With N>1 ranks (torchrun, one per GPU) every rank owns a 10M-point shard of an
-N x 10M cloud and the V/N views whose masks it "produced"; each step all-gathers the masks over
-RCCL (the path's one exchange step) and then fuses its shard -- weak scaling.
+One step = one pass of the hot path over one batch: every point of the cloud is projected into all
+V views, sampled, voted and segmented (f3d_project_vote_argmax_dev), with the inputs already
+resident in HBM.  Workload at N=1: BASELINE.json config C3 (10M points x 64 views, 1024x1024
+masks).  With N>1 ranks (torchrun, one per GPU) the workload is C4 as BASELINE states it: the SAME
+10M points, sharded by contiguous point ranges over the ranks (strong scaling); every rank owns
+the masks of the V/N views it "produced" and each step all-gathers the masks over RCCL (the path's
+one exchange step, double-buffered: the all-gather of step i+1 runs under the kernels of step i)
+and then fuses its shard.  --weak gives every rank its own --points instead.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--filter] [--masks iid|block64]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--filter] [--masks iid|block64] [--weak]
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
@@ -37,10 +39,12 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--points', type=int, default=10_000_000, help='points per GPU (C3: 10M)')
+    ap.add_argument('--points', type=int, default=10_000_000, help='points of the cloud (C3/C4: 10M), sharded over the ranks; per rank with --weak')
+    ap.add_argument('--weak', action='store_true', help='N > 1: every rank owns --points points of an N x larger cloud (weak scaling)')
+    ap.add_argument('--no-merge', action='store_true', help='skip the C5 bbox-merge leg (50M points, 4096 instances)')
     ap.add_argument('--views', type=int, default=64)
     ap.add_argument('--size', type=int, default=1024, help='mask width = height')
-    ap.add_argument('--masks', default='block64', choices=['block64', 'iid'])
+    ap.add_argument('--masks', default='block64', choices=['block64', 'block64x40', 'iid'])
     ap.add_argument('--filter', action='store_true', help='segment with the reference default filter_classes=[86,114,115]')
     ap.add_argument('--f32', action='store_true', help='store xyz as float32 (12 B/point) instead of float64')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -87,7 +91,62 @@ def cpu_baseline(sample, views_n, size, mask_kind, filter_classes):
     dt = time.perf_counter() - t0
     return dict(value=round(sample / dt, 1), unit='points/s', cores=1, kind='port',
                 sample=f'{sample} points x {views_n} views in {dt:.1f} s, one NumPy process ({os.cpu_count()} host cpus visible, '
-                       f'elementwise NumPy only -> 1 core); the path is linear in N'), out, pts, masks
+                       f'elementwise NumPy only -> 1 core); the path is linear in N'), out, pts, masks, (K, q, t)
+
+
+def merge_leg(local):
+    """C5's bbox-merge leg (BASELINE.json config 5, SURVEY 8(d) recipe): 50M points in 4096 Gaussian blobs (sigma 0.15 m, seed 3456),
+    parent = id mod 8, through the drop-in merge_bb; beside it the oracle's literal restatement of the reference control flow
+    (merge_intersecting_bb.py:103-137: O(B^2) refits and full-cloud scans) on a slice of the same recipe, one host core."""
+    import copy
+    import Fusion3DSeg.merge_intersecting_bb as M
+    from oracle import np_ref as O
+
+    def scene(B, n):
+        rng = np.random.default_rng(3456)
+        centres = rng.uniform([-5, -5, 0], [5, 5, 3], (B, 3))
+        ids = rng.integers(1, B, n).astype(np.int64)
+        pts = centres[ids] + rng.normal(size=(n, 3)) * 0.15
+        return pts, ids, [{'id': k, 'category_id': 86, 'parent_id': k % 8, 'area': int((ids == k).sum())} for k in range(B)]
+
+    B, n = 4096, 50_000_000
+    pts, ids, info = scene(B, n)
+    prof = {}
+    keep = M._MergeState.__init__
+
+    def spy(self, *a, **k):
+        keep(self, *a, **k)
+        prof['state'] = self
+    M._MergeState.__init__ = spy
+    try:
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):                  # merge_bb prints its wall time like the reference; stdout carries the JSON line only
+            t0 = time.perf_counter()
+            out_info, _ = M.merge_bb(None, info, ids, pts)
+            dt = time.perf_counter() - t0
+    finally:
+        M._MergeState.__init__ = keep
+    st = prof['state'].prof
+    del pts, ids
+    Bs, ns = 384, 192_000
+    p2, i2, f2 = scene(Bs, ns)
+    t0 = time.perf_counter()
+    o_info, o_ids = O.merge_bb(copy.deepcopy(f2), i2.copy(), p2)
+    dtc = time.perf_counter() - t0
+    with contextlib.redirect_stdout(sys.stderr):
+        g_info, g_ids = M.merge_bb(None, copy.deepcopy(f2), i2.copy(), p2, box_fn=O.obb_from_points)
+    same = bool(np.array_equal(g_ids, o_ids) and [(d['id'], d['area']) for d in g_info] == [(d['id'], d['area']) for d in o_info])
+    return dict(workload=f'C5 merge: {n} points, {B} instances (Gaussian blobs, parent = id mod 8) -> {len(out_info)} entries',
+                seconds=round(dt, 3), points_per_s=round(n / dt, 1),
+                breakdown_s={k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()},
+                algorithmic_bytes_per_scan=24 * n,
+                note='host-pointer call: the 1.2 GB cloud is uploaded inside the timed region (breakdown_s.upload); box fits = host Qhull on the '
+                     'survivors of the GPU inner-hull filter; scans = k_points_in_obb launches',
+                cpu_baseline=dict(value=round(dtc, 2), unit='s', cores=1, kind='port',
+                                  sample=f'oracle/np_ref.py::merge_bb (reference control flow, O(B^2) refits and scans) on {ns} points, {Bs} '
+                                         f'instances of the same recipe; its cost grows like B^2 N / 8, i.e. ~{dtc * (B / Bs) ** 2 * (n / ns) / 3600:.0f} h '
+                                         f'extrapolated to the full C5 shape',
+                                  same_result_as_hip_on_sample=same))
 
 
 def main():
@@ -115,12 +174,22 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
     ctx = f3d.Context(local)
 
-    n, V, S = args.points, args.views, args.size
+    V, S = args.views, args.size
+    if world > 1 and not args.weak:
+        lo, hi = sharding.point_bounds(args.points, rank, world)          # C4: one cloud, contiguous point ranges
+        n, total_points, scaling = hi - lo, args.points, 'strong'
+    else:
+        lo, n, total_points, scaling = 0, args.points, args.points * world, ('weak' if args.weak and world > 1 else 'strong')
+    if n <= 0:
+        raise SystemExit('more ranks than points')
     flt = [86, 114, 115] if args.filter else None
     K = np.array([[800., 0, S / 2], [0, 800., S / 2], [0, 0, 1]])
     q, t = synth.ring_views(V)
     views_np = f3d.views_build(K, S, S, q, t, 10.0)
-    xyz_np = synth.cloud(n, dtype=np.float32 if args.f32 else np.float64, shard=rank)
+    if scaling == 'strong' and world > 1:
+        xyz_np = synth.cloud(args.points, dtype=np.float32 if args.f32 else np.float64)[lo:lo + n]      # this rank's range of THE cloud
+    else:
+        xyz_np = synth.cloud(n, dtype=np.float32 if args.f32 else np.float64, shard=rank)
     if args.sorted:
         cell = np.floor((xyz_np.astype(np.float64) - np.array([-5, -5, 0])) / 0.25).astype(np.int64)
         xyz_np = xyz_np[np.argsort((cell[:, 0] * 64 + cell[:, 1]) * 16 + cell[:, 2], kind='stable')]
@@ -251,37 +320,46 @@ def main():
     xyz_b = 12 if args.f32 else 24
     abytes = algorithmic_bytes(n, V, S, S, xyz_b)
     achieved = abytes / t_kernel / 1e9
-    traffic, traffic_src = None, None
-    pmc = ROOT / 'profiles' / 'r01_pmc_by_kernel.csv'      # PMC passes of this same command (rocprofv3 --pmc, separate runs)
-    if pmc.is_file() and n == 10_000_000 and V == 64 and S == 1024 and not args.f32:
-        vals = {}
-        for line in pmc.read_text().splitlines()[1:]:
-            k, c, v = line.split(',')
-            if k == 'k_fuse':
-                vals[c] = float(v)
-        if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
-            traffic = int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
-            traffic_src = ('profiles/r01_pmc_by_kernel.csv: (FETCH_SIZE + WRITE_SIZE) KB per k_fuse launch, raw (the x2 FETCH_SIZE '
-                           'correction is calibrated for wide streams, not for 1-byte gathers; L2 misses incl. Infinity-Cache hits)')
+    # HBM traffic of the dominant kernel from the PMC passes of THIS build (scripts/pmc_custom.sh; separate rocprofv3 --pmc runs):
+    # the CSV names the library it was taken with, a different build gets null
+    traffic, traffic_src = None, 'no PMC pass of this build under profiles/ (the CSV names another libf3d_hip.so)'
+    import hashlib
+    lib_sha = hashlib.sha256(f3d.library_path().read_bytes()).hexdigest()[:16]
+    pmc = ROOT / 'profiles' / 'r02_pmc_by_kernel.csv'
+    if pmc.is_file() and n == 10_000_000 and V == 64 and S == 1024 and not args.f32 and world == 1:
+        lines = pmc.read_text().splitlines()
+        if lines and lines[0].strip() == f'# lib_sha16={lib_sha}':
+            vals = {}
+            for line in lines[1:]:
+                parts = line.split(',')
+                if len(parts) >= 3 and parts[0] == 'k_fuse':
+                    vals[parts[1]] = float(parts[2])
+            if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+                traffic = int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
+                traffic_src = (f'profiles/r02_pmc_by_kernel.csv (lib {lib_sha}): (FETCH_SIZE + WRITE_SIZE) KB per k_fuse launch, raw (the x2 '
+                               'FETCH_SIZE correction is calibrated for wide streams, not for 1-byte gathers; L2 misses incl. Infinity-Cache hits)')
     roofline = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     kernel='k_fuse', kernel_ms=round(t_kernel * 1e3, 4), sort_ms=round(t_sort * 1e3, 4),
                     algorithmic_bytes=abytes,
-                    valu_frac=round(FLOP_PER_POINT_VIEW * n * V / t_kernel / (FP64_VALU_PEAK_TFLOPS * 1e12), 4),
-                    note='the fused V-view kernel is fp64-VALU bound, not HBM bound (SURVEY 8(d): HBM-fraction ceiling ~7% at '
-                         'V=64); valu_frac = 82 reference flop x N x V / t / 78.6 TF (the kernel executes fewer flop than the '
-                         'reference formulation thanks to tile culling and the fast projection)')
+                    reference_flop_frac=round(FLOP_PER_POINT_VIEW * n * V / t_kernel / (FP64_VALU_PEAK_TFLOPS * 1e12), 4),
+                    note='kernel_ms = the whole fused call (label presence + mask coding + k_fuse + float64 middle tier + exact '
+                         'kernel), HIP events on its stream.  The fused V-view path is instruction-issue / gather bound, not HBM '
+                         'bound (SURVEY 8(d): HBM-fraction ceiling ~7% at V=64).  reference_flop_frac = 82 flop of the REFERENCE '
+                         'formulation x N x V / t / 78.6 TF fp64 -- NOT a utilisation: ~55% of the (wave, view) pairs are culled and '
+                         'never executed, and the executed arithmetic is float32 (profiles/ has the executed-instruction counters)')
 
     out = None
     if rank == 0:
-        total_points = n * world
         out = dict(metric='labelled points/sec (10M pts x 64 views) at 1/2/4/8 GPU; % HBM roofline',
                    value=round(total_points * args.steps / elapsed, 1), unit='points/s', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
-                   config=dict(workload=f'C3: {n} points/GPU x {V} ring views, {S}x{S} {args.masks} uint8 masks, '
-                                        f'nclasses=133, threshold=0.5, filter_classes={flt}; fused project->sample->vote->segment',
-                               points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64', cloud_layout=layout,
+                   higher_is_better=True, scaling=scaling, vs_baseline=None, dtype='f64', data='synthetic',
+                   config=dict(workload=(f'C3: {total_points} points x {V} ring views' if world == 1 else
+                                         f'C4: {total_points} points sharded over {world} GPUs ({scaling} scaling) x {V} ring views') +
+                                        f', {S}x{S} {args.masks} uint8 masks, nclasses=133, threshold=0.5, filter_classes={flt}; '
+                                        f'fused project->sample->vote->segment',
+                               points_total=total_points, points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64', cloud_layout=layout,
                                deferred_points=dict(to_float64_tier=deferred[0], to_exact_kernel=deferred[1]),
                                exchange='none' if not use_dist else f'RCCL all_gather of {V // world} masks/rank per step, double-buffered and overlapped with the previous step'),
                    roofline=roofline)
@@ -289,14 +367,18 @@ def main():
     # secondary, HBM-streaming kernels of the same path (not part of `value`)
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
-        uv = torch.empty((2, n), dtype=torch.int32, device=dev)
-        ins = torch.empty(n, dtype=torch.uint8, device=dev)
-        tk = time_kernel(torch, lambda: ctx.project_view_dev(xyz.data_ptr(), dtype, n, views_np[0], uv.data_ptr(), ins.data_ptr(),
-                                                             stream.cuda_stream), 10, stream)
-        b = (xyz_b + 8 + 1) * n
+        # the per-point streaming kernels run on a 50M-point cloud (1.2 GB of xyz, 1.65 GB per pass): far beyond the 256 MiB
+        # Infinity Cache, so that GB/s is HBM traffic and not cache hits across the timed repeats
+        nbig = 50_000_000
+        big = torch.from_numpy(synth.cloud(nbig, dtype=np.float32 if args.f32 else np.float64)).to(dev)
+        uv = torch.empty((2, nbig), dtype=torch.int32, device=dev)
+        ins = torch.empty(nbig, dtype=torch.uint8, device=dev)
+        tk = time_kernel(torch, lambda: ctx.project_view_dev(big.data_ptr(), dtype, nbig, views_np[0], uv.data_ptr(), ins.data_ptr(),
+                                                             stream.cuda_stream), 5, stream)
+        b = (xyz_b + 8 + 1) * nbig
         extras['project_view (a2+a4, 1 view)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
-                                                        bytes_per_point=xyz_b + 9)
-        del uv, ins
+                                                        bytes_per_point=xyz_b + 9, points=nbig)
+        del uv
         ns = min(n, 4_000_000)
         votes = torch.zeros((ns, 134), dtype=torch.float64, device=dev)
         votes.view(-1)[::7] = 3.0
@@ -327,16 +409,16 @@ def main():
         extras['sem_logits_to_mask (a9, 133x1024x1024)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
                                                                   bytes_per_pixel=533)
         del sem, mk
-        # a1 / a4 single-purpose streaming kernels
-        ins = torch.empty(n, dtype=torch.uint8, device=dev)
+        # a4 single-purpose streaming kernel, same 50M-point working set
         F = f3d.view_fields(views_np)
         pp, pn = np.ascontiguousarray(F['plane_pt'][0]), np.ascontiguousarray(F['plane_n'][0])
-        if not args.f32:
-            tk = time_kernel(torch, lambda: ctx._check(ctx._lib.f3d_inside_polyhedra_dev(ctx._h, xyz.data_ptr(), dtype, n, pp.ctypes.data, pn.ctypes.data, 5,
-                                                                                       ins.data_ptr(), stream.cuda_stream)), 10, stream)
-            b = (xyz_b + 1) * n
-            extras['inside_polyhedra (a4, 5 planes)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
-                                                             bytes_per_point=xyz_b + 1)
+        tk = time_kernel(torch, lambda: ctx._check(ctx._lib.f3d_inside_polyhedra_dev(ctx._h, big.data_ptr(), dtype, nbig, pp.ctypes.data, pn.ctypes.data, 5,
+                                                                                   ins.data_ptr(), stream.cuda_stream)), 5, stream)
+        b = (xyz_b + 1) * nbig
+        extras['inside_polyhedra (a4, 5 planes)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                                         bytes_per_point=xyz_b + 1, points=nbig)
+        del big, ins
+        ins = torch.empty(n, dtype=torch.uint8, device=dev)
         # (f)#3: one 1024x1024 16-bit depth frame -> world points
         dep = torch.randint(0, 6000, (S, S), device=dev, dtype=torch.int16)       # < 32768: the same bits as uint16
         wpts = torch.empty((S * S, 3), dtype=torch.float64, device=dev)
@@ -358,12 +440,26 @@ def main():
         del ins, cooc
         out['streaming_kernels'] = extras
 
+    if rank == 0 and world == 1 and not args.no_merge and not args.no_extras:
+        out['merge_bb'] = merge_leg(local)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:          # reported at N=1 only
-        cb, cls_cpu, pts_cpu, masks_cpu = cpu_baseline(args.cpu_sample, V, S, args.masks, flt)
+        from oracle import np_ref as O
+        cb, cls_cpu, pts_cpu, masks_cpu, (K, q, t) = cpu_baseline(args.cpu_sample, V, S, args.masks, flt)
         out['cpu_baseline'] = cb
-        # the same sample through the HIP path must give the same labels
-        got = f3d.default_context(local).project_vote_argmax(pts_cpu, views_np, masks_cpu, 133, 0.5, flt)
-        out['parity_on_cpu_sample'] = bool(np.array_equal(got, cls_cpu))
+        # the same sample through the HIP path must give the same labels -- at the bench's threshold AND at threshold 0, where
+        # every sampled point carries a real label (at 0.5 with independent random masks ~99.9 % are 133 = "unclassified")
+        hctx = f3d.default_context(local)
+        got = hctx.project_vote_argmax(pts_cpu, views_np, masks_cpu, 133, 0.5, flt)
+        sub = min(len(pts_cpu), 1_000_000)
+        want0, wvotes = O.project_vote_argmax(pts_cpu[:sub], K, q, t, masks_cpu, 10.0, 133, 0.0, flt, return_votes=True)
+        got0, gvotes = hctx.project_vote_argmax(pts_cpu[:sub], views_np, masks_cpu, 133, 0.0, flt, return_votes=True)
+        out['parity_on_cpu_sample'] = bool(np.array_equal(got, cls_cpu) and np.array_equal(got0, want0) and
+                                           np.array_equal(gvotes.astype(np.float64), wvotes))
+        out['parity_detail'] = dict(threshold_0p5=dict(points=len(pts_cpu), equal=bool(np.array_equal(got, cls_cpu)),
+                                                       real_label_fraction=round(float((cls_cpu != 133).mean()), 5)),
+                                    threshold_0p0=dict(points=sub, equal=bool(np.array_equal(got0, want0)), votes_equal=bool(np.array_equal(gvotes.astype(np.float64), wvotes)),
+                                                       real_label_fraction=round(float((want0 != 133).mean()), 5)))
     elif rank == 0:
         out['cpu_baseline'] = None
 
