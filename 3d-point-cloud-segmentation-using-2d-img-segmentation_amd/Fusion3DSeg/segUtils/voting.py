@@ -78,16 +78,31 @@ class VotingSegmentation:
         session = _DeviceVotes(ctx, self.votes)
         if verbose:
             print('voting ... ')
+        # frames are read on the host and handed to the GPU a batch at a time: one upload of all lookups and masks, one
+        # kernel pair for the batch (f3d_vote_uv2pt_batch*) instead of two copies and three launches per frame
+        batch_l, batch_m, pending_error = [], [], None
         for i in range(self.nframes):
             if verbose:
                 print(f'frame/total = {i + 1}/{self.nframes}, progress = {((i + 1) * 100 / self.nframes):.3}%')
             mask, uv2pt = self._read_data(i)
             mask = resize_nearest(mask, w, h) if resize else mask
-            mask = np.ascontiguousarray(mask).reshape(-1)
-            if (np.asarray(uv2pt) != -1).any():
-                session.add_frame(uv2pt, mask)
+            mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+            lut = np.asarray(uv2pt, dtype=np.int32).reshape(-1)
+            if len(lut) != len(mask):                       # NumPy raises at this frame; the earlier ones stay applied
+                pending_error = IndexError(f'boolean index did not match: uv2pt has {len(lut)} entries, the mask {len(mask)}')
+                break
+            if len(lut) != h * w:                           # a lookup of another size than depth_hw: its own single-frame call
+                session.add_frames(batch_l, batch_m, h, w); batch_l, batch_m = [], []
+                session.add_frame(lut, mask)
+                continue
+            batch_l.append(lut); batch_m.append(mask)
+            if len(batch_l) * h * w >= 1 << 26:             # ~64 frames of 1024^2: bound the host staging memory
+                session.add_frames(batch_l, batch_m, h, w); batch_l, batch_m = [], []
+        session.add_frames(batch_l, batch_m, h, w)
         try:
             self.votes = session.download()
+            if pending_error is not None:
+                raise pending_error
         except IndexError:
             self.votes = session.download(check=False)      # frames before the offending one stay applied, as in the reference
             raise
@@ -114,7 +129,7 @@ class _DeviceVotes:
 
     def __init__(self, ctx, votes):
         self.ctx, self.host = ctx, np.ascontiguousarray(votes, dtype=np.float64)
-        self.torch = None
+        self.torch, self.error = None, None
         try:
             import torch
             if torch.cuda.is_available():
@@ -125,13 +140,38 @@ class _DeviceVotes:
         except ImportError:
             pass
 
+    def add_frames(self, luts, masks, h, w):
+        """Frames of h*w lookups each, in order, as ONE batched call."""
+        if not luts:
+            return
+        lut = np.ascontiguousarray(np.stack(luts), dtype=np.int32)
+        m = np.ascontiguousarray(np.stack(masks), dtype=np.uint8)
+        if self.torch is None:
+            if self.error is not None:                                  # the reference stopped at the offending frame
+                return
+            try:
+                self.ctx.vote_uv2pt_batch(self.host, lut, m, h, w)
+            except IndexError as exc:                                   # frames before the offending one are applied, like NumPy
+                self.error = self.error or exc
+            return
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            dl = torch.from_numpy(lut).to(self.dev)
+            dm = torch.from_numpy(m).to(self.dev)
+            self.ctx.vote_uv2pt_batch_dev(dl.data_ptr(), dm.data_ptr(), len(lut), h, w, self.t.data_ptr(), self.t.shape[0], self.t.shape[1],
+                                          self.stream.cuda_stream)
+
     def add_frame(self, uv2pt, mask_flat):
         lut = np.array(uv2pt, dtype=np.int32).reshape(-1)               # private, writable copies
         m = np.array(mask_flat, dtype=np.uint8).reshape(-1)
         if len(lut) != len(m):
             raise IndexError(f'boolean index did not match: uv2pt has {len(lut)} entries, the mask {len(m)}')
         if self.torch is None:
-            self.ctx.vote_uv2pt(self.host, lut, m)
+            if self.error is None:
+                try:
+                    self.ctx.vote_uv2pt(self.host, lut, m)
+                except IndexError as exc:
+                    self.error = exc
             return
         torch = self.torch
         with torch.cuda.stream(self.stream):
@@ -145,6 +185,8 @@ class _DeviceVotes:
 
     def download(self, check=True):
         if self.torch is None:
+            if check and self.error is not None:
+                raise self.error
             return self.host
         self.stream.synchronize()
         if check:

@@ -41,6 +41,9 @@ struct f3d_ctx {
     long long allocs;                   // device allocations made by this context so far (f3d_ctx_alloc_count)
     unsigned long long* table;          // open-addressing set of the uv2pt vote
     size_t table_slots;
+    unsigned vote_gen;                  // generation stamp of the batched vote's set entries (the set is cleared when it wraps)
+    bool table_stamped;                 // the table holds generation-stamped entries only (else: clear before a batched call)
+    int* first_bad;                     // device int: first frame of the current batched call with an out-of-range index
     int* filter_dev;                    // filter_classes of the call being enqueued (device copy)
     int32_t filter_host[F3D_MAX_FILTER];  // its staging copy: must outlive the asynchronous upload
     unsigned long long* count_dev;
@@ -223,6 +226,7 @@ f3d_ctx* f3d_ctx_create(int device) {
               hipMalloc((void**)&ctx->filter_dev, sizeof(int32_t) * F3D_MAX_FILTER) == hipSuccess &&
               hipMalloc((void**)&ctx->count_dev, sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&ctx->codebook, sizeof(f3d_codebook)) == hipSuccess &&
+              hipMalloc((void**)&ctx->first_bad, sizeof(int)) == hipSuccess &&
               hipMemset(ctx->dev_err, 0, sizeof(int)) == hipSuccess;
     if (!ok) {
         fail(nullptr, F3D_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -242,6 +246,7 @@ void f3d_ctx_destroy(f3d_ctx* ctx) {
     if (ctx->filter_dev) (void)hipFree(ctx->filter_dev);
     if (ctx->count_dev) (void)hipFree(ctx->count_dev);
     if (ctx->codebook) (void)hipFree(ctx->codebook);
+    if (ctx->first_bad) (void)hipFree(ctx->first_bad);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -639,6 +644,7 @@ static int ensure_table(f3d_ctx* ctx, int64_t hw) {
         if (ctx->table) { F3D_HIP(ctx, hipFree(ctx->table)); ctx->table = nullptr; ctx->table_slots = 0; }
         F3D_HIP(ctx, hipMalloc((void**)&ctx->table, want * sizeof(unsigned long long)));
         ctx->table_slots = want;
+        ctx->table_stamped = false;
         ++ctx->allocs;
     }
     return F3D_OK;
@@ -654,7 +660,59 @@ int f3d_vote_uv2pt_dev(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, 
     size_t slots = 1024;
     while (slots < (size_t)hw * 2) slots <<= 1;
     F3D_HIP(ctx, f3d_launch_vote_uv2pt(uv2pt, mask, hw, votes, npts, ncols, ctx->table, slots, ctx->dev_err, pick(ctx, stream)));
+    ctx->table_stamped = false;                               // raw keys in the table: a batched call clears it first
     return F3D_OK;
+}
+
+int f3d_vote_uv2pt_batch_dev(f3d_ctx* ctx, const int32_t* luts, const uint8_t* masks, int64_t nframes, int h, int w, double* votes,
+                             int64_t npts, int ncols, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t hw = (int64_t)h * w;
+    if (nframes < 0 || h < 0 || w < 0 || npts < 0 || npts >= ((int64_t)1 << 31) || ncols <= 0 || ncols > 256 ||
+        (nframes > 0 && hw > 0 && (!luts || !masks || !votes)))
+        return fail(ctx, F3D_ERR_INVALID, "vote_uv2pt_batch: bad arguments (npts < 2^31, ncols <= 256)");
+    if (nframes == 0 || hw == 0) return F3D_OK;
+    hipStream_t s = pick(ctx, stream);
+    // frames per launch: at most 1023 (10 bits of the key) and at most 2^25 lookups (a 512 MiB set at load <= 1/2)
+    int64_t per = ((int64_t)1 << 25) / hw;
+    if (per < 1) per = 1;
+    if (per > 1023) per = 1023;
+    const int64_t first = nframes < per ? nframes : per;
+    if ((rc = ensure_table(ctx, first * hw))) return rc;
+    F3D_HIP(ctx, hipMemsetAsync(ctx->first_bad, 0x7f, sizeof(int), s));                        // 0x7f7f7f7f: no bad frame
+    for (int64_t f0 = 0; f0 < nframes; f0 += per) {
+        const int nf = (int)(nframes - f0 < per ? nframes - f0 : per);
+        if (!ctx->table_stamped || ctx->vote_gen >= 16382u) {
+            F3D_HIP(ctx, hipMemsetAsync(ctx->table, 0xFF, ctx->table_slots * sizeof(unsigned long long), s));   // generation 0x3FFF = never current
+            ctx->table_stamped = true; ctx->vote_gen = 0;
+        }
+        const unsigned gen = ctx->vote_gen++;
+        size_t slots = 1024;
+        while (slots < (size_t)nf * hw * 2) slots <<= 1;      // the share of the table this launch hashes into (<= table_slots)
+        F3D_HIP(ctx, f3d_launch_vote_uv2pt_batch(luts + f0 * hw, masks + f0 * hw, nf, h, w, votes, npts, ncols, ctx->table, slots, gen, (int)f0,
+                                                 ctx->first_bad, ctx->dev_err, s));
+    }
+    return F3D_OK;
+}
+
+int f3d_vote_uv2pt_batch(f3d_ctx* ctx, const int32_t* luts, const uint8_t* masks, int64_t nframes, int h, int w, double* votes,
+                         int64_t npts, int ncols) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t hw = (int64_t)h * w;
+    if (nframes < 0 || h < 0 || w < 0 || npts < 0 || ncols <= 0 || (nframes > 0 && hw > 0 && (!luts || !masks || !votes)))
+        return fail(ctx, F3D_ERR_INVALID, "vote_uv2pt_batch: bad arguments");
+    if (nframes == 0 || hw == 0) return F3D_OK;
+    const size_t vbytes = (size_t)npts * ncols * 8, lb = (size_t)nframes * hw * 4, mb = (size_t)nframes * hw;
+    void *dlut, *dmask, *dvotes;
+    if ((rc = ensure(ctx, SLOT_AUX0, lb, &dlut)) || (rc = ensure(ctx, SLOT_AUX1, mb, &dmask)) || (rc = ensure(ctx, SLOT_OUT1, vbytes, &dvotes))) return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dlut, luts, lb, hipMemcpyHostToDevice, s));                    // every frame's lookup in ONE copy
+    F3D_HIP(ctx, hipMemcpyAsync(dmask, masks, mb, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dvotes, votes, vbytes, hipMemcpyHostToDevice, s));             // the matrix travels once per BATCH, not per frame
+    if ((rc = f3d_vote_uv2pt_batch_dev(ctx, (const int32_t*)dlut, (const uint8_t*)dmask, nframes, h, w, (double*)dvotes, npts, ncols, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(votes, dvotes, vbytes, hipMemcpyDeviceToHost, s));             // frames before a bad one stay applied, like NumPy
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return take_error(ctx, s, F3D_DEVERR_VOTE);
 }
 
 int f3d_vote_uv2pt(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols) {

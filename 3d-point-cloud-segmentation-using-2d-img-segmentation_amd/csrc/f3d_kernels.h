@@ -119,6 +119,10 @@ hipError_t f3d_launch_segment_votes(const double* votes, int64_t npts, int ncols
                                     const f3d_filter_args& flt, int64_t* classes, hipStream_t s);
 hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int64_t hw, double* votes, int64_t npts, int ncols,
                                  unsigned long long* table, uint64_t table_slots, int* err, hipStream_t s);
+// batched vote: frames [frame0, frame0 + nframes) of a call; table slots carry `gen` (< 16383), first_bad = device int (INT_MAX = none)
+hipError_t f3d_launch_vote_uv2pt_batch(const int32_t* luts, const uint8_t* masks, int nframes, int h, int w, double* votes, int64_t npts,
+                                       int ncols, unsigned long long* table, uint64_t table_slots, unsigned gen, int frame0, int* first_bad,
+                                       int* err, hipStream_t s);
 hipError_t f3d_launch_sem_to_mask(const float* sem, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s);
 hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, uint32_t* bits,
                                     uint8_t* cooc, hipStream_t s);

@@ -198,6 +198,99 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_vote_uv2pt(const int32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// a7, batched: F frames of the uv2pt scatter vote in one launch (VotingSegmentation.vote's loop, voting.py:88-98).
+// Quirk Q1 holds PER FRAME (a (point, label) pair adds 1 per frame however many of the frame's pixels carry it), so the
+// de-duplication key is (frame, point, label).  Three levels, cheapest first:
+//   1. a block owns a 32 x 32 pixel tile of one frame and de-duplicates in an LDS set -- a fused point's pixels are a patch
+//      window (fusion.py:269-298), i.e. they sit next to each other, so most duplicates die here without touching HBM;
+//   2. the survivors enter a global open-addressing set whose slots carry a GENERATION stamp: [14 bit generation | 10 bit
+//      frame | 39 bit point * ncols + label].  A slot of an older generation counts as empty, so the set is never cleared
+//      between calls (the per-frame entry point memsets 16 MiB per 1024^2 frame);
+//   3. the lane whose insert creates the key adds 1 to the vote cell (float64 atomic: two frames of a batch may hit one cell).
+// NumPy raises IndexError for the first frame with an out-of-range index and leaves the earlier frames applied: pass 1 finds
+// the first bad frame of the batch, pass 2 skips it and everything after it.
+// ------------------------------------------------------------------------------------------
+#define F3D_VOTE_TILE 32
+#define F3D_VOTE_LDS_SLOTS 2048
+#define F3D_VOTE_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__global__ __launch_bounds__(F3D_BLOCK) void k_vote_validate_batch(const int32_t* __restrict__ luts, const uint8_t* __restrict__ masks,
+                                                                    int64_t nframes, int64_t hw, int64_t npts, int ncols, int frame0,
+                                                                    int* __restrict__ first_bad) {
+    int bad = 0x7fffffff;
+    const int64_t total = nframes * hw;
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t p = luts[i];
+        if (p == -1) continue;
+        if (p >= npts || p < -npts || (int)masks[i] >= ncols) { const int f = frame0 + (int)(i / hw); bad = f < bad ? f : bad; }
+    }
+    if (bad != 0x7fffffff) atomicMin(first_bad, bad);
+}
+
+__global__ __launch_bounds__(F3D_BLOCK) void k_vote_uv2pt_batch(const int32_t* __restrict__ luts, const uint8_t* __restrict__ masks,
+                                                                 int nframes, int h, int w, int tiles_x, int tiles_y,
+                                                                 double* __restrict__ votes, int64_t npts, int ncols,
+                                                                 unsigned long long* __restrict__ table, uint64_t table_mask, unsigned gen,
+                                                                 int frame0, const int* __restrict__ first_bad, int* __restrict__ err) {
+    __shared__ unsigned long long lset[F3D_VOTE_LDS_SLOTS];
+    if (*err & F3D_DEVERR_VOTE) return;                               // an earlier, untaken IndexError: nothing is written any more
+    const int fb = *first_bad;
+    const int tiles = tiles_x * tiles_y;
+    const int64_t hw = (int64_t)h * w;
+    for (int64_t b = blockIdx.x; b < (int64_t)nframes * tiles; b += gridDim.x) {
+        const int f = (int)(b / tiles), t = (int)(b - (int64_t)f * tiles);
+        if (frame0 + f >= fb) {                                       // the reference raised at frame fb: this frame never ran
+            if (frame0 + f == fb && t == 0 && threadIdx.x == 0) atomicOr(err, F3D_DEVERR_VOTE);
+            continue;
+        }
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        for (int k = threadIdx.x; k < F3D_VOTE_LDS_SLOTS; k += F3D_BLOCK) lset[k] = F3D_VOTE_EMPTY;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < (F3D_VOTE_TILE * F3D_VOTE_TILE) / F3D_BLOCK; ++r) {
+            const int local = r * F3D_BLOCK + threadIdx.x;
+            const int y = ty * F3D_VOTE_TILE + local / F3D_VOTE_TILE, x = tx * F3D_VOTE_TILE + (local & (F3D_VOTE_TILE - 1));
+            if (y >= h || x >= w) continue;
+            const int64_t i = (int64_t)f * hw + (int64_t)y * w + x;
+            int64_t p = luts[i];
+            if (p == -1) continue;
+            if (p < 0) p += npts;                                     // NumPy negative-index wrap
+            const unsigned long long cell = (unsigned long long)p * (unsigned long long)ncols + masks[i];   // < 2^39
+            // 1. block-local set
+            unsigned ls = (unsigned)((cell * 0x9E3779B97F4A7C15ull) >> 40);
+            bool fresh = false;
+            for (;;) {
+                ls &= F3D_VOTE_LDS_SLOTS - 1;
+                const unsigned long long prev = atomicCAS(&lset[ls], F3D_VOTE_EMPTY, cell);
+                if (prev == F3D_VOTE_EMPTY) { fresh = true; break; }
+                if (prev == cell) break;
+                ++ls;
+            }
+            if (!fresh) continue;
+            // 2. global generation-stamped set
+            const unsigned long long mine = ((unsigned long long)gen << 49) | ((unsigned long long)f << 39) | cell;
+            uint64_t slot = (mine * 0x9E3779B97F4A7C15ull) >> 20;
+            bool created = false;
+            for (;;) {
+                slot &= table_mask;
+                unsigned long long cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == mine) break;
+                if ((unsigned)(cur >> 49) != gen) {                  // empty or left over from an earlier call: claim it
+                    const unsigned long long prev = atomicCAS(&table[slot], cur, mine);
+                    if (prev == cur) { created = true; break; }
+                    if (prev == mine) break;
+                    continue;                                         // somebody else took the slot meanwhile: look at it again
+                }
+                ++slot;
+            }
+            // 3. the creator of the key votes
+            if (created) atomicAdd(&votes[cell], 1.0);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // a9: [C, HW] float32 logits -> uint8 mask (get2DSeg.py:110-118).  HBM streaming: 4*C B in, 1 B out per pixel.
 // A thread owns 4 consecutive pixels and walks the C class planes once with 16-B loads (a wave reads 1 KiB
 // contiguous per plane, 8 planes in flight): running argmax (first maximum) and an online softmax denominator
@@ -428,6 +521,20 @@ hipError_t f3d_launch_vote_uv2pt(const int32_t* uv2pt, const uint8_t* mask, int6
     const dim3 g(grid_for(hw, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
     hipLaunchKernelGGL(k_vote_validate, g, b, 0, s, uv2pt, mask, hw, npts, ncols, err);
     hipLaunchKernelGGL(k_vote_uv2pt, g, b, 0, s, uv2pt, mask, hw, votes, npts, ncols, table, (uint64_t)(table_slots - 1), err);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_vote_uv2pt_batch(const int32_t* luts, const uint8_t* masks, int nframes, int h, int w, double* votes, int64_t npts,
+                                       int ncols, unsigned long long* table, uint64_t table_slots, unsigned gen, int frame0, int* first_bad,
+                                       int* err, hipStream_t s) {
+    if (nframes <= 0 || h <= 0 || w <= 0) return hipSuccess;
+    const int64_t hw = (int64_t)h * w;
+    hipLaunchKernelGGL(k_vote_validate_batch, dim3(grid_for(hw * nframes, F3D_BLOCK, F3D_GRID_CAP)), dim3(F3D_BLOCK), 0, s, luts, masks, (int64_t)nframes, hw,
+                       npts, ncols, frame0, first_bad);
+    const int tx = (w + F3D_VOTE_TILE - 1) / F3D_VOTE_TILE, ty = (h + F3D_VOTE_TILE - 1) / F3D_VOTE_TILE;
+    const int64_t blocks = (int64_t)nframes * tx * ty;
+    hipLaunchKernelGGL(k_vote_uv2pt_batch, dim3((unsigned)(blocks < 1048576 ? blocks : 1048576)), dim3(F3D_BLOCK), 0, s, luts, masks, nframes, h, w, tx, ty,
+                       votes, npts, ncols, table, (uint64_t)(table_slots - 1), gen, frame0, first_bad, err);
     return hipGetLastError();
 }
 

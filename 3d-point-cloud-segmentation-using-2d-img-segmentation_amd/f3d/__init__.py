@@ -88,6 +88,8 @@ def library():
         'f3d_take_device_error': (i32, [vp, vp]),
         'f3d_vote_uv2pt': (i32, [vp, vp, vp, i64, vp, i64, i32]),
         'f3d_vote_uv2pt_dev': (i32, [vp, vp, vp, i64, vp, i64, i32, vp]),
+        'f3d_vote_uv2pt_batch': (i32, [vp, vp, vp, i64, i32, i32, vp, i64, i32]),
+        'f3d_vote_uv2pt_batch_dev': (i32, [vp, vp, vp, i64, i32, i32, vp, i64, i32, vp]),
         'f3d_segment_votes': (i32, [vp, vp, i64, i32, i32, dbl, vp, i32, vp]),
         'f3d_segment_votes_dev': (i32, [vp, vp, i64, i32, i32, dbl, vp, i32, vp, vp]),
         'f3d_sem_logits_to_mask': (i32, [vp, vp, i32, i64, flt, i32, vp]),
@@ -324,6 +326,18 @@ class Context:
         self._check(self._lib.f3d_vote_uv2pt(self._h, _ptr(lut), _ptr(m), len(lut), _ptr(votes), votes.shape[0], votes.shape[1]))
         return votes
 
+    def vote_uv2pt_batch(self, votes, luts, masks, h, w):
+        """All frames of VotingSegmentation.vote in one call, in place on `votes` (float64 [npts, ncols], C-contiguous);
+        luts int32 [F, h*w], masks uint8 [F, h*w]."""
+        if votes.dtype != np.float64 or not votes.flags.c_contiguous or votes.ndim != 2:
+            raise ValueError('votes must be a C-contiguous float64 [npts, ncols] array')
+        lut = np.ascontiguousarray(luts, dtype=np.int32).reshape(-1, h * w)
+        m = np.ascontiguousarray(masks, dtype=np.uint8).reshape(-1, h * w)
+        if lut.shape != m.shape:
+            raise IndexError(f'shape mismatch: lookups {lut.shape}, masks {m.shape}')
+        self._check(self._lib.f3d_vote_uv2pt_batch(self._h, _ptr(lut), _ptr(m), len(lut), int(h), int(w), _ptr(votes), votes.shape[0], votes.shape[1]))
+        return votes
+
     def segment_votes(self, votes, nclasses, threshold=0.5, filter_classes=None):
         v = _f64(votes)
         if v.ndim != 2:
@@ -550,6 +564,9 @@ class Context:
 
     def vote_uv2pt_dev(self, uv2pt_ptr, mask_ptr, hw, votes_ptr, npts, ncols, stream=None):
         self._check(self._lib.f3d_vote_uv2pt_dev(self._h, uv2pt_ptr, mask_ptr, hw, votes_ptr, npts, ncols, stream))
+
+    def vote_uv2pt_batch_dev(self, luts_ptr, masks_ptr, nframes, h, w, votes_ptr, npts, ncols, stream=None):
+        self._check(self._lib.f3d_vote_uv2pt_batch_dev(self._h, luts_ptr, masks_ptr, int(nframes), int(h), int(w), votes_ptr, npts, ncols, stream))
 
     def sem_logits_to_mask_dev(self, sem_ptr, c, hw, conf, low_label, mask_ptr, stream=None):
         self._check(self._lib.f3d_sem_logits_to_mask_dev(self._h, sem_ptr, c, hw, float(conf or 0.0), int(low_label), mask_ptr, stream))

@@ -388,19 +388,39 @@ def main():
         extras['segment_votes (a8)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
                                              bytes_per_point=1080, points=ns)
         del votes, cls2
-        # a7: one frame of the uv2pt scatter vote (1024x1024 lookup, ~70 % valid, 4M points)
+        # a7: the uv2pt scatter vote, 1024x1024 lookups, ~70 % valid, 4M points: frame by frame (3 launches + a 16 MiB memset each)
+        # against the batched call (one launch pair for all frames), on lookups without any duplication (random: every pixel its own
+        # point -- the worst case, two scattered atomics per pixel whatever the schedule) and on patch-structured ones (every fused
+        # point owns a 5x5 pixel patch, as Fusion.fuse writes them: duplicates die in LDS)
         hw = S * S
         rng = np.random.default_rng(7)
-        lut_np = rng.integers(0, ns, hw).astype(np.int32); lut_np[rng.random(hw) < 0.3] = -1
-        lut = torch.from_numpy(lut_np).to(dev)
+        Fv = 16
         votes = torch.zeros((ns, 134), dtype=torch.float64, device=dev)
-        m0 = masks_full[0].reshape(-1)
-        tk = time_kernel(torch, lambda: ctx.vote_uv2pt_dev(lut.data_ptr(), m0.data_ptr(), hw, votes.data_ptr(), ns, 134, stream.cuda_stream), 10, stream)
-        nvalid = int((lut_np != -1).sum())
-        b = 5 * hw + 16 * nvalid
-        extras['vote_uv2pt (a7, 1 frame 1024x1024)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
-                                                            note='5 B/pixel streamed + 8 B read + 8 B write per vote at random rows (scatter: line-granular traffic is ~8x that)')
-        del votes, lut
+        mv = masks_full[:Fv].reshape(Fv, -1)
+        for kind in ('random', 'patch5x5'):
+            if kind == 'random':
+                lut_np = rng.integers(0, ns, (Fv, hw)).astype(np.int32)
+            else:
+                cells = rng.integers(0, ns, (Fv, (S + 4) // 5, (S + 4) // 5)).astype(np.int32)
+                lut_np = np.repeat(np.repeat(cells, 5, 1), 5, 2)[:, :S, :S].reshape(Fv, hw).copy()
+            lut_np[rng.random((Fv, hw)) < 0.3] = -1
+            lut = torch.from_numpy(lut_np).to(dev)
+            nvalid = int((lut_np != -1).sum()) // Fv
+
+            def per_frame():
+                for f in range(Fv):
+                    ctx.vote_uv2pt_dev(lut[f].data_ptr(), mv[f].data_ptr(), hw, votes.data_ptr(), ns, 134, stream.cuda_stream)
+            tk1 = time_kernel(torch, per_frame, 3, stream) / Fv
+            tkb = time_kernel(torch, lambda: ctx.vote_uv2pt_batch_dev(lut.data_ptr(), mv.data_ptr(), Fv, S, S, votes.data_ptr(), ns, 134, stream.cuda_stream),
+                              3, stream) / Fv
+            b = 5 * hw + 16 * nvalid
+            extras[f'vote_uv2pt (a7, 1024x1024 frames, {kind} lookups)'] = dict(
+                per_frame_ms=round(tk1 * 1e3, 4), batched_ms_per_frame=round(tkb * 1e3, 4), frames_per_s_per_frame_api=round(1 / tk1, 1),
+                frames_per_s_batched=round(1 / tkb, 1), speedup=round(tk1 / tkb, 2), GBps_batched=round(b / tkb / 1e9, 1),
+                hbm_frac_batched=round(b / tkb / 1e9 / HBM_PEAK_GBS, 4),
+                note='algorithmic bytes: 5 B/pixel streamed + 8 B read + 8 B write per valid lookup (scatter: line-granular traffic is ~8x that)')
+            del lut
+        del votes
         # a9: logits -> mask for one 133 x 1024 x 1024 image
         sem = torch.randn((133, S, S), dtype=torch.float32, device=dev)
         mk = torch.empty((S, S), dtype=torch.uint8, device=dev)

@@ -224,6 +224,16 @@ int f3d_vote_uv2pt(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int6
 int f3d_vote_uv2pt_dev(f3d_ctx* ctx, const int32_t* uv2pt, const uint8_t* mask, int64_t hw,
                        double* votes, int64_t npts, int ncols, void* stream);
 
+/* The whole loop of VotingSegmentation.vote (voting.py:88-98) for F frames of h x w pixels in one call: luts int32 [F, h*w],
+ * masks uint8 [F, h*w] (already at the lookup's resolution).  Same result as F calls of f3d_vote_uv2pt in frame order, incl.
+ * the IndexError semantics: the frames before the first offending one are applied, it and the later ones are not
+ * (F3D_ERR_INDEX from the host variant; the _dev variant records it for f3d_take_device_error).  One launch pair per 2^25
+ * lookups; duplicates die in an LDS set per 32 x 32 tile, the global set is generation-stamped and never cleared. */
+int f3d_vote_uv2pt_batch(f3d_ctx* ctx, const int32_t* luts, const uint8_t* masks, int64_t nframes, int h, int w,
+                         double* votes, int64_t npts, int ncols);
+int f3d_vote_uv2pt_batch_dev(f3d_ctx* ctx, const int32_t* luts, const uint8_t* masks, int64_t nframes, int h, int w,
+                             double* votes, int64_t npts, int ncols, void* stream);
+
 /* ---- a8: VotingSegmentation.segment (voting.py:106-137) ----------------------------------- */
 int f3d_segment_votes(f3d_ctx* ctx, const double* votes, int64_t npts, int ncols, int nclasses,
                       double threshold, const int32_t* filter, int nfilter, int64_t* classes);

@@ -174,6 +174,78 @@ def test_vote_and_segment_larger_random(ctx):
         assert np.array_equal(ctx.segment_votes(votes, 133, thr, flt), O.segment(want, 133, thr, flt))
 
 
+def _patch_luts(rng, nframes, h, w, npts, patch=5):
+    """Lookups as Fusion.fuse writes them: every fused point owns a patch of neighbouring pixels (heavy duplication per frame)."""
+    luts = np.full((nframes, h, w), -1, np.int32)
+    for f in range(nframes):
+        cells = rng.integers(0, npts, ((h + patch - 1) // patch, (w + patch - 1) // patch)).astype(np.int32)
+        lut = np.repeat(np.repeat(cells, patch, 0), patch, 1)[:h, :w].copy()
+        lut[rng.random((h, w)) < 0.3] = -1
+        luts[f] = lut
+    return luts.reshape(nframes, -1)
+
+
+def test_vote_uv2pt_batch_equals_frame_by_frame(ctx, golden):
+    """f3d_vote_uv2pt_batch*: the whole loop of VotingSegmentation.vote in one call -- equal to the reference's votes (voting.npz),
+    to the oracle frame by frame on random and patch-structured lookups, across launch chunks (> 1023 frames), on repeated calls
+    (generation-stamped set, never cleared) and interleaved with the per-frame entry point."""
+    g = golden('voting')
+    votes = np.zeros_like(g['votes'])
+    h, w = g['masks'].shape[1:]
+    ctx.vote_uv2pt_batch(votes, g['uv2pt'], g['masks'].reshape(len(g['masks']), -1), h, w)
+    assert np.array_equal(votes, g['votes'])
+    rng = np.random.default_rng(12)
+    npts, h, w, ncols, F = 20000, 96, 130, 134, 7                      # w not a multiple of the 32-pixel tile
+    for kind in ('random', 'patch'):
+        luts = rng.integers(-1, npts, (F, h * w)).astype(np.int32) if kind == 'random' else _patch_luts(rng, F, h, w, npts)
+        luts[2, 100:400] = luts[2, 100]                                # one pair many times
+        luts[3, :5] = [-2, -1, -npts, npts - 1, 0]                     # NumPy negative indices wrap
+        masks = rng.choice(synth.ALPHABET, (F, h * w)).astype(np.uint8)
+        want = np.zeros((npts, ncols))
+        for f in range(F):
+            O.vote_frame(want, luts[f], masks[f])
+        got = np.zeros((npts, ncols))
+        ctx.vote_uv2pt_batch(got, luts, masks, h, w)
+        assert np.array_equal(got, want), kind
+        ctx.vote_uv2pt_batch(got, luts, masks, h, w)                   # again on the same context: adds the same increments once more
+        assert np.array_equal(got, 2 * want), kind
+        ctx.vote_uv2pt(got, luts[0], masks[0])                         # the per-frame call in between (it clears the shared set)
+        ctx.vote_uv2pt_batch(got, luts[1:], masks[1:], h, w)
+        assert np.array_equal(got, 3 * want), kind
+    # more frames than one launch takes (1023): small frames
+    F, h, w, npts = 1100, 40, 48, 3000
+    luts = _patch_luts(rng, F, h, w, npts, patch=3)
+    masks = rng.integers(0, 6, (F, h * w)).astype(np.uint8)
+    want = np.zeros((npts, 6))
+    for f in range(F):
+        O.vote_frame(want, luts[f], masks[f])
+    got = np.zeros((npts, 6))
+    ctx.vote_uv2pt_batch(got, luts, masks, h, w)
+    assert np.array_equal(got, want) and want.max() > 50
+
+
+def test_vote_uv2pt_batch_index_error_keeps_the_earlier_frames(ctx):
+    rng = np.random.default_rng(13)
+    npts, h, w, F = 500, 33, 40, 6
+    luts = rng.integers(-1, npts, (F, h * w)).astype(np.int32)
+    masks = rng.integers(0, 4, (F, h * w)).astype(np.uint8)
+    for bad_kind in ('label', 'point'):
+        l2, m2 = luts.copy(), masks.copy()
+        if bad_kind == 'label':
+            m2[3, 77] = 9; l2[3, 77] = 5                               # label 9 >= 4 columns, on a valid lookup
+        else:
+            l2[3, 77] = npts
+        want = np.zeros((npts, 4))
+        for f in range(3):                                             # NumPy raises at frame 3: frames 0-2 are applied, 3-5 never run
+            O.vote_frame(want, l2[f], m2[f])
+        got = np.zeros((npts, 4))
+        with pytest.raises(IndexError):
+            ctx.vote_uv2pt_batch(got, l2, m2, h, w)
+        assert np.array_equal(got, want), bad_kind
+        ctx.vote_uv2pt_batch(got, luts[:3], masks[:3], h, w)           # the context is usable again
+        assert np.array_equal(got, 2 * want)
+
+
 def _dev_fuse(ctx, pts, views, masks, flt, thr, flags, presort=False, f32=False, nclasses=133, mask_shift=0, votes_at=None):
     """One call of f3d_project_vote_argmax_dev on device-resident inputs.  votes_at: caller-order indices whose uint16 vote
     rows are returned as well (the full [n, nclasses + 1] matrix stays on the device)."""
