@@ -184,28 +184,26 @@ class Fusion:
                                                     pcdimg, pt2u, pt2v, free)
         prio = np.empty(len(points), np.int32)
         prio[order] = np.arange(len(points), dtype=np.int32)
-        owner, _ = f3d.default_context().patch_seeds(points, normals, prio, flat_free, height, width, half, max_distance, min_cosine)
+        # seeds, what each of them takes, and the ordered sums of those rows (a thread per seed adds its members in ascending pixel
+        # index = the reference's window order, so the means are bit-identical): one call, the frame uploaded once
+        colors = np.asarray(colors, np.float64)
+        owner, sums, counts, _ = f3d.default_context().patch_seeds_sums(points, normals, colors, prio, flat_free, height, width, half,
+                                                                        max_distance, min_cosine)
         uv2pt = np.full(height * width, -1, np.int32)
-        taken = np.nonzero(owner >= 0)[0]                                    # ascending pixel id = row-major order inside every window
-        if not len(taken):
+        seeds = np.nonzero(owner == np.arange(height * width, dtype=np.int32))[0]
+        if not len(seeds):
             return np.array([]), np.array([]), np.array([]), uv2pt, np.array([])
-        by_seed = np.argsort(prio[owner[taken]], kind='stable')              # seeds in visiting order, members ascending inside
-        members = taken[by_seed]
-        _, first, n_take = np.unique(prio[owner[members]], return_index=True, return_counts=True)
-
-        def mean_in_order(rows):                                             # per seed ((r0 + r1) + r2) + ... then / n, as np.mean does
-            acc = rows[first].copy()
-            for r in range(1, int(n_take.max())):
-                more = n_take > r
-                acc[more] += rows[first[more] + r]
-            return acc / n_take[:, None]
-
-        colors = np.asarray(colors)
-        out_p, out_c, nsum = mean_in_order(points[members]), mean_in_order(colors[members]), mean_in_order(normals[members])
+        seeds = seeds[np.argsort(prio[seeds], kind='stable')]                # seeds in visiting order = output order
+        n_take = counts[seeds].astype(np.int64)
+        mean = sums[seeds] / n_take[:, None]                                 # np.mean: the ordered sum, then one division
+        out_p, nsum, out_c = mean[:, 0:3], mean[:, 3:6], mean[:, 6:9]
         out_n = nsum / _row_norms(nsum)[:, None]
-        uv2pt[members] = np.repeat(np.arange(len(first), dtype=np.int32), n_take)
-        free[pt2v[members], pt2u[members]] = False
-        return out_p, out_n, out_c, uv2pt, n_take
+        rank = np.empty(height * width, np.int32)
+        rank[seeds] = np.arange(len(seeds), dtype=np.int32)
+        taken = owner >= 0
+        uv2pt[taken] = rank[owner[taken]]
+        free.reshape(-1)[taken] = False
+        return np.ascontiguousarray(out_p), out_n, np.ascontiguousarray(out_c), uv2pt, n_take
 
     @staticmethod
     def _patch_downsample_sequential(order, points, normals, colors, height, width, half, max_distance, min_cosine, pcdimg, pt2u, pt2v, free):
@@ -272,29 +270,23 @@ class Fusion:
                 # The reference visits the seeds in index order and lets each take the free pixels of its window that pass the
                 # criterion (:269-298).  A seed's criterion uses its own position / normal from BEFORE this frame, so the result
                 # is: a free pixel belongs to the first seed whose window covers it and accepts it -- one HIP launch.
-                owner = ctx.patch_owner(uv, x_pts, x_nrm, q_pts, q_nrm, free.reshape(-1), self.h, self.w, half, radius, min_cosine)
-                taken = np.nonzero(owner >= 0)[0]                           # ascending pixel id = row-major order inside every window
-                if len(taken):
-                    by_seed = np.argsort(owner[taken], kind='stable')
-                    members, seed_of = taken[by_seed], owner[taken][by_seed]
-                    seeds, first, n_take = np.unique(seed_of, return_index=True, return_counts=True)
-
-                    def sum_in_order(rows):                                 # per seed: ((r0 + r1) + r2) + ..., as np.mean adds rows
-                        acc = rows[first].copy()
-                        for r in range(1, int(n_take.max())):
-                            more = n_take > r
-                            acc[more] += rows[first[more] + r]
-                        return acc
-
+                # ... followed, on the resident frame, by one thread per seed that adds the rows of the pixels it took in ascending
+                # pixel index (((r0 + r1) + r2) + ..., the order np.mean adds the reference's vstack in)
+                owner, sums, counts = ctx.patch_match(uv, x_pts, x_nrm, q_pts, q_nrm, q_clr, free.reshape(-1), self.h, self.w, half, radius,
+                                                      min_cosine)
+                seeds = np.nonzero(counts)[0]
+                if len(seeds):
+                    n_take = counts[seeds].astype(np.int64)
                     denom = (n_take + 1)[:, None]                           # the seed itself is the last row of the reference's vstack
-                    x_pts[seeds] = (sum_in_order(q_pts[members]) + x_pts[seeds]) / denom
-                    x_clr[seeds] = (sum_in_order(q_clr[members]) + x_clr[seeds]) / denom
-                    nsum = (sum_in_order(q_nrm[members]) + x_nrm[seeds]) / denom
+                    x_pts[seeds] = (sums[seeds, 0:3] + x_pts[seeds]) / denom
+                    x_clr[seeds] = (sums[seeds, 6:9] + x_clr[seeds]) / denom
+                    nsum = (sums[seeds, 3:6] + x_nrm[seeds]) / denom
                     x_nrm[seeds] = nsum / _row_norms(nsum)[:, None]
                     x_mrg[seeds] += n_take
                     x_occ[seeds] += 1
-                    uv2pt[members] = ids[seed_of]
-                    free[self.pt2v[members], self.pt2u[members]] = False
+                    taken = owner >= 0
+                    uv2pt[taken] = ids[owner[taken]]
+                    free.reshape(-1)[taken] = False
                 pts[hits], nrm[hits], clr[hits] = x_pts, x_nrm, x_clr
                 nmerges[hits], occurences[hits] = x_mrg, x_occ
             if free.any():                                                    # (as in the reference, `free` of an earlier frame if none hit)

@@ -1072,6 +1072,87 @@ int f3d_patch_seeds(f3d_ctx* ctx, const double* pts, const double* nrm, const in
     return F3D_OK;
 }
 
+// The matching of one frame of Fusion.fuse with the ordered sums of what every seed takes: the frame is uploaded once, the owner and
+// the sums kernels run back to back on the resident arrays (colours optional).
+int f3d_patch_match(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w, int half, double radius, double min_cosine,
+                    const double* seed_pts, const double* seed_nrm, const double* q_pts, const double* q_nrm, const double* q_clr,
+                    const uint8_t* free_px, int32_t* owner, double* sums, int32_t* counts) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t npx = (int64_t)h * w;
+    if (h < 0 || w < 0 || m < 0 || half < 0 || npx > 0x7fffffffLL || m > 0x7fffffffLL || (m > 0 && (!uv || !seed_pts || !seed_nrm || !sums || !counts)) ||
+        (npx > 0 && (!q_pts || !q_nrm || !free_px || !owner)))
+        return fail(ctx, F3D_ERR_INVALID, "patch_match: bad arguments");
+    if (npx == 0) return F3D_OK;
+    void *duv, *dsp, *dsn, *dqp, *dqn, *dqc, *dfree, *down, *dsum, *scratch;
+    if ((rc = ensure(ctx, SLOT_AUX0, (size_t)m * 8 + 8, &duv)) || (rc = ensure(ctx, SLOT_XYZ, (size_t)m * 24 + 8, &dsp)) ||
+        (rc = ensure(ctx, SLOT_OUT1, (size_t)m * 24 + 8, &dsn)) || (rc = ensure(ctx, SLOT_MASKS, (size_t)npx * 24, &dqp)) ||
+        (rc = ensure(ctx, SLOT_VIEWS, (size_t)npx * 24, &dqn)) || (rc = ensure(ctx, SLOT_TILED_MASKS, (size_t)npx * 24, &dqc)) ||
+        (rc = ensure(ctx, SLOT_AUX1, (size_t)npx, &dfree)) || (rc = ensure(ctx, SLOT_OUT0, (size_t)npx * 4, &down)) ||
+        (rc = ensure(ctx, SLOT_GRAPH, (size_t)m * 76 + 16, &dsum)) || (rc = ensure(ctx, SLOT_PATCH, f3d_patch_scratch_bytes(h, w, m), &scratch)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    if (m) {
+        F3D_HIP(ctx, hipMemcpyAsync(duv, uv, (size_t)m * 8, hipMemcpyHostToDevice, s));
+        F3D_HIP(ctx, hipMemcpyAsync(dsp, seed_pts, (size_t)m * 24, hipMemcpyHostToDevice, s));
+        F3D_HIP(ctx, hipMemcpyAsync(dsn, seed_nrm, (size_t)m * 24, hipMemcpyHostToDevice, s));
+    }
+    F3D_HIP(ctx, hipMemcpyAsync(dqp, q_pts, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dqn, q_nrm, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    if (q_clr) F3D_HIP(ctx, hipMemcpyAsync(dqc, q_clr, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dfree, free_px, (size_t)npx, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, f3d_launch_patch_owner((const int32_t*)duv, m, h, w, half, radius, min_cosine, (const double*)dsp, (const double*)dsn, (const double*)dqp,
+                                        (const double*)dqn, (const uint8_t*)dfree, (int32_t*)down, scratch, s));
+    double* dsums = (double*)dsum;
+    int32_t* dcnt = (int32_t*)((char*)dsum + (((size_t)m * 72 + 15) & ~(size_t)15));
+    F3D_HIP(ctx, f3d_launch_patch_sums((const int32_t*)down, (const int32_t*)duv, m, h, w, half, (const double*)dqp, (const double*)dqn,
+                                       q_clr ? (const double*)dqc : nullptr, dsums, dcnt, s));
+    F3D_HIP(ctx, hipMemcpyAsync(owner, down, (size_t)npx * 4, hipMemcpyDeviceToHost, s));
+    if (m) {
+        F3D_HIP(ctx, hipMemcpyAsync(sums, dsums, (size_t)m * 72, hipMemcpyDeviceToHost, s));
+        F3D_HIP(ctx, hipMemcpyAsync(counts, dcnt, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    }
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
+// patch_downsample with the ordered sums of every seed's members (sums [h*w, 9], counts [h*w]; only the self-owning pixels carry values)
+int f3d_patch_seeds_sums(f3d_ctx* ctx, const double* pts, const double* nrm, const double* clr, const int32_t* prio, const uint8_t* free_px,
+                         int h, int w, int half, double radius, double min_cosine, int32_t* owner, double* sums, int32_t* counts,
+                         int32_t* rounds) {
+    int rc = enter(ctx); if (rc) return rc;
+    const int64_t npx = (int64_t)h * w;
+    if (h < 0 || w < 0 || half < 0 || npx > 0x7fffffffLL || (npx > 0 && (!pts || !nrm || !prio || !free_px || !owner || !sums || !counts)))
+        return fail(ctx, F3D_ERR_INVALID, "patch_seeds_sums: bad arguments");
+    if (rounds) *rounds = 0;
+    if (npx == 0) return F3D_OK;
+    void *dp, *dn, *dc, *dprio, *dfree, *dstat, *down, *dsum;
+    if ((rc = ensure(ctx, SLOT_MASKS, (size_t)npx * 24, &dp)) || (rc = ensure(ctx, SLOT_VIEWS, (size_t)npx * 24, &dn)) ||
+        (rc = ensure(ctx, SLOT_TILED_MASKS, (size_t)npx * 24, &dc)) || (rc = ensure(ctx, SLOT_AUX0, (size_t)npx * 4, &dprio)) ||
+        (rc = ensure(ctx, SLOT_AUX1, (size_t)npx, &dfree)) || (rc = ensure(ctx, SLOT_PATCH, (size_t)npx * 4 + 256, &dstat)) ||
+        (rc = ensure(ctx, SLOT_OUT0, (size_t)npx * 4, &down)) || (rc = ensure(ctx, SLOT_GRAPH, (size_t)npx * 76 + 16, &dsum)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    F3D_HIP(ctx, hipMemcpyAsync(dp, pts, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dn, nrm, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    if (clr) F3D_HIP(ctx, hipMemcpyAsync(dc, clr, (size_t)npx * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dprio, prio, (size_t)npx * 4, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dfree, free_px, (size_t)npx, hipMemcpyHostToDevice, s));
+    int r = 0;
+    int32_t* counter = (int32_t*)((char*)dstat + (((size_t)npx * 4 + 63) & ~(size_t)63));
+    F3D_HIP(ctx, f3d_launch_patch_seeds((const double*)dp, (const double*)dn, (const int32_t*)dprio, (const uint8_t*)dfree, h, w, half, radius,
+                                        min_cosine, (int32_t*)dstat, (int32_t*)down, counter, &r, s));
+    double* dsums = (double*)dsum;
+    int32_t* dcnt = (int32_t*)((char*)dsum + (((size_t)npx * 72 + 15) & ~(size_t)15));
+    F3D_HIP(ctx, f3d_launch_patch_sums((const int32_t*)down, nullptr, npx, h, w, half, (const double*)dp, (const double*)dn, clr ? (const double*)dc : nullptr,
+                                       dsums, dcnt, s));
+    F3D_HIP(ctx, hipMemcpyAsync(owner, down, (size_t)npx * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipMemcpyAsync(sums, dsums, (size_t)npx * 72, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipMemcpyAsync(counts, dcnt, (size_t)npx * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    if (rounds) *rounds = r;
+    return F3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // (f)#1 adjacency: KDTree(points).query_radius(points, r) (fusion.py:374-375) as CSR
 // ---------------------------------------------------------------------------------------------

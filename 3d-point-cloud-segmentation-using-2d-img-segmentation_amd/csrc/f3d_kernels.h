@@ -104,6 +104,10 @@ hipError_t f3d_launch_patch_owner(const int32_t* uv, int64_t m, int h, int w, in
 hipError_t f3d_launch_patch_seeds(const double* pts, const double* nrm, const int32_t* prio, const uint8_t* free_px, int h, int w, int half,
                                   double radius, double min_cosine, int32_t* status, int32_t* owner, int32_t* counter, int* rounds,
                                   hipStream_t s);
+// ordered per-seed sums of the rows of up to three [h*w, 3] arrays over the pixels each seed owns (uv != NULL: seeds of Fusion.fuse at
+// their projections, m of them; uv == NULL: the self-owning pixels of patch_downsample, m = h*w); sums [m, 9], counts [m]
+hipError_t f3d_launch_patch_sums(const int32_t* owner, const int32_t* uv, int64_t m, int h, int w, int half, const double* rows_a,
+                                 const double* rows_b, const double* rows_c, double* sums, int32_t* counts, hipStream_t s);
 // a12: remaining intersections.py primitives (f3d_geom.hip), device pointers
 hipError_t f3d_launch_ray_x_lines(const double o[3], const double d[3], const double* starts, const double* ends, int64_t n, double* pts,
                                   uint8_t* within, hipStream_t s);

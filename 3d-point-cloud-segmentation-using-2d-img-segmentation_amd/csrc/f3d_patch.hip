@@ -164,6 +164,47 @@ __global__ __launch_bounds__(PB) void k_pd_owner(const double* __restrict__ pts,
     }
 }
 
+// ---- ordered per-seed sums (fusion.py:195-201, 289-298).  The reference stacks a seed's accepted pixels in window order
+// (row-major = ascending pixel index) and takes np.mean, i.e. adds the rows one after the other: ((r0 + r1) + r2) + ...  One
+// thread per seed walks its window in that order and adds the rows of the pixels it owns -- the same additions in the same
+// order, so the means come out bit for bit.  FUSE: seed k sits at its projection uv[:, k] (Python slice window); otherwise a
+// seed is a pixel that owns itself (patch_downsample) and the window is clamped to the image.
+template <bool FUSE>
+__global__ __launch_bounds__(PB) void k_patch_sums(const int32_t* __restrict__ owner, const int32_t* __restrict__ uv, int64_t m, patch_args a,
+                                                    const double* __restrict__ ra, const double* __restrict__ rb, const double* __restrict__ rc,
+                                                    double* __restrict__ sums, int32_t* __restrict__ counts) {
+    for (int64_t k = (int64_t)blockIdx.x * PB + threadIdx.x; k < m; k += (int64_t)gridDim.x * PB) {
+        int r0, r1, c0, c1;
+        if (FUSE) {
+            py_slice(uv[m + k], a.half, a.h, r0, r1);
+            py_slice(uv[k], a.half, a.w, c0, c1);
+        } else {
+            if (owner[k] != (int32_t)k) { counts[k] = 0; continue; }
+            const int v = (int)(k / a.w), u = (int)(k - (int64_t)v * a.w);
+            r0 = max(0, v - a.half); r1 = min(a.h, v + a.half + 1); c0 = max(0, u - a.half); c1 = min(a.w, u + a.half + 1);
+        }
+        double acc[9];
+        int n = 0;
+        for (int y = r0; y < r1; ++y)
+            for (int x = c0; x < c1; ++x) {
+                const int64_t p = (int64_t)y * a.w + x;
+                if (owner[p] != (int32_t)k) continue;
+                if (n == 0) {
+                    for (int c = 0; c < 3; ++c) { acc[c] = ra ? ra[3 * p + c] : 0.0; acc[3 + c] = rb ? rb[3 * p + c] : 0.0; acc[6 + c] = rc ? rc[3 * p + c] : 0.0; }
+                } else {
+                    for (int c = 0; c < 3; ++c) {
+                        if (ra) acc[c] += ra[3 * p + c];
+                        if (rb) acc[3 + c] += rb[3 * p + c];
+                        if (rc) acc[6 + c] += rc[3 * p + c];
+                    }
+                }
+                ++n;
+            }
+        counts[k] = n;
+        if (n) for (int c = 0; c < 9; ++c) sums[9 * k + c] = acc[c];
+    }
+}
+
 inline int blocks_for(int64_t n) { int64_t b = (n + PB - 1) / PB; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
 struct patch_layout { size_t count, start, cursor, bucket, odd, nodd, temp, total; };
@@ -234,5 +275,14 @@ hipError_t f3d_launch_patch_seeds(const double* pts, const double* nrm, const in
         if (left == 0) break;
     }
     hipLaunchKernelGGL(k_pd_owner, g, b, 0, s, pts, nrm, prio, a, status, owner);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_patch_sums(const int32_t* owner, const int32_t* uv, int64_t m, int h, int w, int half, const double* rows_a,
+                                 const double* rows_b, const double* rows_c, double* sums, int32_t* counts, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    patch_args a; a.h = h; a.w = w; a.half = half; a.radius = 0; a.min_cosine = 0;
+    if (uv) hipLaunchKernelGGL(k_patch_sums<true>, dim3(blocks_for(m)), dim3(PB), 0, s, owner, uv, m, a, rows_a, rows_b, rows_c, sums, counts);
+    else hipLaunchKernelGGL(k_patch_sums<false>, dim3(blocks_for(m)), dim3(PB), 0, s, owner, uv, m, a, rows_a, rows_b, rows_c, sums, counts);
     return hipGetLastError();
 }

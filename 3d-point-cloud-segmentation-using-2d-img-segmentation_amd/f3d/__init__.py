@@ -115,6 +115,8 @@ def library():
         'f3d_patch_owner': (i32, [vp, vp, i64, i32, i32, i32, dbl, dbl, vp, vp, vp, vp, vp, vp]),
         'f3d_patch_owner_dev': (i32, [vp, vp, i64, i32, i32, i32, dbl, dbl, vp, vp, vp, vp, vp, vp, vp]),
         'f3d_patch_seeds': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, dbl, dbl, vp, vp]),
+        'f3d_patch_match': (i32, [vp, vp, i64, i32, i32, i32, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'f3d_patch_seeds_sums': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, dbl, dbl, vp, vp, vp, vp]),
         'f3d_unproject_depth': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp]),
         'f3d_unproject_depth_dev': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp, vp]),
         'f3d_radius_graph_count': (i32, [vp, vp, i32, i64, dbl, vp, vp]),
@@ -498,6 +500,36 @@ class Context:
         self._check(self._lib.f3d_patch_seeds(self._h, _ptr(qp), _ptr(qn), _ptr(pr), _ptr(fr), h, w, int(half), float(radius), float(min_cosine),
                                               _ptr(owner), C.byref(rounds)))
         return owner, rounds.value
+
+    def patch_match(self, uv, seed_pts, seed_normals, frame_pts, frame_normals, frame_colors, free, h, w, half, radius, min_cosine):
+        """patch_owner plus, per seed, the ordered sums of the frame rows it takes: (owner int32 [h*w], sums float64 [m, 9] =
+        points | normals | colours, counts int32 [m])."""
+        uv = np.ascontiguousarray(uv, dtype=np.int32)
+        sp, sn = _f64(seed_pts), _f64(seed_normals)
+        qp, qn = _f64(frame_pts, (h * w, 3)), _f64(frame_normals, (h * w, 3))
+        qc = None if frame_colors is None else _f64(frame_colors, (h * w, 3))
+        fr = np.ascontiguousarray(free, dtype=np.uint8).reshape(-1)
+        m = len(sp)
+        if uv.shape != (2, m) or sn.shape != (m, 3) or len(fr) != h * w:
+            raise ValueError('patch_match: uv must be [2,m], seeds [m,3], free [h*w]')
+        owner, sums, counts = np.empty(h * w, np.int32), np.zeros((m, 9)), np.zeros(m, np.int32)
+        self._check(self._lib.f3d_patch_match(self._h, _ptr(uv), m, h, w, int(half), float(radius), float(min_cosine), _ptr(sp), _ptr(sn),
+                                              _ptr(qp), _ptr(qn), _ptr(qc), _ptr(fr), _ptr(owner), _ptr(sums), _ptr(counts)))
+        return owner, sums, counts
+
+    def patch_seeds_sums(self, frame_pts, frame_normals, frame_colors, prio, free, h, w, half, radius, min_cosine):
+        """patch_seeds plus the ordered sums per seed pixel: (owner int32 [h*w], sums float64 [h*w, 9], counts int32 [h*w], rounds)."""
+        qp, qn = _f64(frame_pts, (h * w, 3)), _f64(frame_normals, (h * w, 3))
+        qc = None if frame_colors is None else _f64(frame_colors, (h * w, 3))
+        pr = np.ascontiguousarray(prio, dtype=np.int32).reshape(-1)
+        fr = np.ascontiguousarray(free, dtype=np.uint8).reshape(-1)
+        if len(pr) != h * w or len(fr) != h * w:
+            raise ValueError('patch_seeds_sums: prio and free must have h*w entries')
+        owner, sums, counts = np.empty(h * w, np.int32), np.zeros((h * w, 9)), np.zeros(h * w, np.int32)
+        rounds = C.c_int32(0)
+        self._check(self._lib.f3d_patch_seeds_sums(self._h, _ptr(qp), _ptr(qn), _ptr(qc), _ptr(pr), _ptr(fr), h, w, int(half), float(radius),
+                                                   float(min_cosine), _ptr(owner), _ptr(sums), _ptr(counts), C.byref(rounds)))
+        return owner, sums, counts, rounds.value
 
     def unproject_depth(self, depth, K, q_wxyz, t, depth_scale=1000.0):
         """Depth frame [H,W] (uint16, float32 or float64) -> world points float64 [H*W,3] (ios_rtab.py:171-173,187-192)."""

@@ -362,6 +362,18 @@ int f3d_patch_seeds(f3d_ctx* ctx, const double* frame_pts, const double* frame_n
                     const uint8_t* free_px, int h, int w, int half, double radius, double min_cosine,
                     int32_t* owner, int32_t* rounds);
 
+/* The same two steps with the ORDERED SUMS of what every seed takes (fusion.py:195-201, 289-298: np.mean over the accepted pixels
+ * stacked in window order): one thread per seed adds the rows of its pixels in ascending pixel index, the order NumPy adds them in,
+ * so the fused points / normals / colours stay bit-identical.  sums double [.., 9] = rows of frame_pts, frame_normals, frame_colors
+ * (colours may be NULL -> zeros), counts int32 = pixels taken.  f3d_patch_match: per seed (m rows); f3d_patch_seeds_sums: per pixel
+ * (h*w rows, meaningful where owner[p] == p).  The frame is uploaded once per call. */
+int f3d_patch_match(f3d_ctx* ctx, const int32_t* uv, int64_t m, int h, int w, int half, double radius, double min_cosine,
+                    const double* seed_pts, const double* seed_normals, const double* frame_pts, const double* frame_normals,
+                    const double* frame_colors, const uint8_t* free_px, int32_t* owner, double* sums, int32_t* counts);
+int f3d_patch_seeds_sums(f3d_ctx* ctx, const double* frame_pts, const double* frame_normals, const double* frame_colors,
+                         const int32_t* prio, const uint8_t* free_px, int h, int w, int half, double radius, double min_cosine,
+                         int32_t* owner, double* sums, int32_t* counts, int32_t* rounds);
+
 /* ---- (f)#3: depth frame -> world points (RTAB_utils/ios_rtab.py) -------------------------- */
 /* RTAB2Cache.__getRGBP3d (:171-173): x = (px - cx) * (d / fx), y = (py - cy) * (d / fy), z = d with the scaled
  * intrinsics K and the integer pixel grid; __getModP3d: divided by depth_scale (1000: mm -> m, :187), rotated by the
