@@ -24,7 +24,7 @@ namespace {
 
 enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_SORT_PERM, SLOT_SORT_SCRATCH,
        SLOT_TILED_MASKS, SLOT_TODO, SLOT_GRAPH, SLOT_GRAPH_BBOX, SLOT_PATCH,
-       SLOT_GRP_ORDER, SLOT_GRP_KEYS, SLOT_GRP_STARTS, SLOT_GRP_SCRATCH, SLOT_OBB_TABLE, SLOT_OBB_FACETS, SLOT_OBB_CAND, SLOT_COUNT };
+       SLOT_GRP_ORDER, SLOT_GRP_KEYS, SLOT_GRP_STARTS, SLOT_GRP_SCRATCH, SLOT_OBB_TABLE, SLOT_OBB_FACETS, SLOT_OBB_CAND, SLOT_FUSE_TABLES, SLOT_COUNT };
 
 thread_local char g_create_err[512] = "";
 
@@ -274,6 +274,7 @@ int f3d_ctx_reserve(f3d_ctx* ctx, int64_t n, int nviews, int h, int w) {
     if (!rc && n > 0) rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &p);
     if (!rc && nviews > 0 && h > 0 && w > 0) rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &p);
     if (!rc && h > 0 && w > 0) rc = ensure_table(ctx, (int64_t)h * w);
+    if (!rc) rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews > 0 ? nviews : 1), &p);
     ctx->strict = strict;
     return rc;
 }
@@ -558,8 +559,10 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
     }
     void* todo;                                                                                 // grows on first use only
     if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
+    void* tables;                                                                               // grows on first use only
+    if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews > 0 ? nviews : 1), &tables))) return rc;
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,
-                                 ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), ctx->codebook, s));
+                                 ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), ctx->codebook, tables, s));
     return F3D_OK;
 }
 

@@ -607,7 +607,20 @@ __device__ __forceinline__ float wave_reduce(float v) {
 #ifndef F3D_FUSE_WAVES
 #define F3D_FUSE_WAVES 3                 // waves per SIMD the register allocation of k_fuse must allow (4 spills: measured slower)
 #endif
-template <typename T, int PPL, bool WRITE_VOTES, bool BIN32, bool WRAP>
+// [group][field][view] copies of the per-view constants the lanes-over-views prologue reads (24 floats: cull planes, margins, image
+// size; 15 doubles: M, t, mnorm), for the instance that cannot afford them in LDS: consecutive lanes read consecutive addresses
+__global__ __launch_bounds__(F3D_BLOCK) void k_views_tables(const f3d_view* __restrict__ views, int nviews, float* __restrict__ ctabT,
+                                                             double* __restrict__ vtabT) {
+    const int ngroups = (nviews + 63) >> 6;
+    for (int k = blockIdx.x * F3D_BLOCK + threadIdx.x; k < ngroups * 64 * 39; k += gridDim.x * F3D_BLOCK) {
+        const int v = k / 39, f = k - v * 39, g = v >> 6, l = v & 63;
+        const f3d_view& vw = views[v < nviews ? v : nviews - 1];
+        if (f < 24) ctabT[(g * 24 + f) * 64 + l] = reinterpret_cast<const float*>(&vw.cull_n32[0][0])[f];
+        else vtabT[(g * F3D_VHEAD + (f - 24)) * 64 + l] = reinterpret_cast<const double*>(&vw)[f - 24];
+    }
+}
+
+template <typename T, int PPL, bool WRITE_VOTES, bool BIN32, bool WRAP, bool TLDS>
 __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
                                                      const uint8_t* __restrict__ cmasks, int H, int W,
@@ -615,16 +628,19 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                                                      int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
                                                      int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
                                                      unsigned int* __restrict__ todo_count, int32_t* __restrict__ todo,
-                                                     const f3d_codebook* __restrict__ cb, int cmin, int cmax) {
+                                                     const f3d_codebook* __restrict__ cb, int cmin, int cmax,
+                                                     const float* __restrict__ ctabT, const double* __restrict__ vtabT) {
     const int ncodes = cb->ncodes;                                        // wave-uniform: scalar load
     if (ncodes > cmax || ncodes < cmin) return;                           // the other instance's book
     const int words = (ncodes + 3) >> 2;
     const int hdw = BIN32 ? ncodes : words;                               // histogram dwords per point
     extern __shared__ uint32_t lds_u32[];
+    // TLDS: the per-view constants of a 64-view group are staged in LDS; otherwise (the any-alphabet instance, whose histograms need the
+    // room) they are read from the transposed global tables ctabT / vtabT
     float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes (+ image size) of one view group
-    uint32_t* lutw = lds_u32 + 64 * F3D_CULL_ROW;                         // lut[256] then inv[256] (bytes)
+    uint32_t* lutw = TLDS ? lds_u32 + 64 * F3D_CULL_ROW : lds_u32;        // lut[256] then inv[256] (bytes)
     double* vtab = reinterpret_cast<double*>(lutw + 128);                 // [F3D_VHEAD][64]: M, t, mnorm of the group's views
-    uint32_t* hist = lutw + 128 + 2 * F3D_VHEAD * 64;                     // [2][hdw][F3D_BLOCK]
+    uint32_t* hist = TLDS ? lutw + 128 + 2 * F3D_VHEAD * 64 : lutw + 128; // [PPL][hdw][F3D_BLOCK]
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
     const uint8_t* inv = lut + 256;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
@@ -650,7 +666,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             vtab[f * 64 + vi] = reinterpret_cast<const double*>(&views[64 * g + vi])[f];
         }
     };
-    if (ngroups == 1) stage_group(0);
+    if (TLDS && ngroups == 1) stage_group(0);
     __syncthreads();
 
     // XCD-aware tile mapping: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so XCD x walks the
@@ -715,19 +731,21 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
         };
 
         for (int g = 0; g < ngroups; ++g) {
-            if (ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
+            if (TLDS && ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
             // lane j <-> view 64g + j: classify the wave's box against that view's planes, project the box centre
             const int vj = 64 * g + lane;
             bool box_out = false, box_in = true, own_image = false;
             float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f, pb3 = 0.f, pb4 = 0.f, pmarg = 0.f;    // (B): n . (c - plane point) per plane, margin
             if (vj < nviews) {
-                const float* row = ctab + lane * F3D_CULL_ROW;
-                const float marg = 2.0f * __builtin_fmaf(row[20], ps_box, row[21]);
+                // field f of this lane's view: LDS row (odd stride) or the transposed global table
+                const float* rowp = TLDS ? ctab + lane * F3D_CULL_ROW : ctabT + (size_t)g * 24 * 64 + lane;
+                auto rowf = [&](int f) { return TLDS ? rowp[f] : rowp[f * 64]; };
+                const float marg = 2.0f * __builtin_fmaf(rowf(20), ps_box, rowf(21));
                 float bmax = 0.f, smax = 0.f, base[F3D_NPLANES];
 #pragma unroll
                 for (int m = 0; m < F3D_NPLANES; ++m) {
-                    const float n0 = row[3 * m], n1 = row[3 * m + 1], n2 = row[3 * m + 2];
-                    base[m] = __builtin_fmaf(n0, c0, __builtin_fmaf(n1, c1, __builtin_fmaf(n2, c2, -row[15 + m])));
+                    const float n0 = rowf(3 * m), n1 = rowf(3 * m + 1), n2 = rowf(3 * m + 2);
+                    base[m] = __builtin_fmaf(n0, c0, __builtin_fmaf(n1, c1, __builtin_fmaf(n2, c2, -rowf(15 + m))));
                     const float spread = __builtin_fmaf(fabsf(n0), e0, __builtin_fmaf(fabsf(n1), e1, fabsf(n2) * e2));
                     box_out = box_out | (base[m] + spread < -marg);
                     box_in = box_in & (base[m] - spread > marg);
@@ -738,11 +756,12 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 // 2^-24 (4 |base| + 5 sum |n_j| E_j).
                 pb0 = base[0]; pb1 = base[1]; pb2 = base[2]; pb3 = base[3]; pb4 = base[4];
                 pmarg = 0.5f * marg + 1.01f * (float)F3D_U24 * (4.0f * bmax + 5.0f * smax);
-                own_image = (row[22] == Wf) & (row[23] == Hf);    // the frustum was built for this mask size: inside the planes = inside the image
+                own_image = (int)(rowf(22) == Wf) & (int)(rowf(23) == Hf);  // the frustum was built for this mask size: inside the planes = inside the image
             }
             centre_row mine = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0, 0};
             bool row_ok = false;
-            if (vj < nviews && !box_out && wave_any) row_ok = centre_precompute(vtab + lane, 64, c0, c1, c2, e0, e1, e2, umaxf, pitch, mine);
+            if (vj < nviews && !box_out && wave_any)
+                row_ok = centre_precompute(TLDS ? vtab + lane : vtabT + (size_t)g * F3D_VHEAD * 64 + lane, 64, c0, c1, c2, e0, e1, e2, umaxf, pitch, mine);
             mine.obase += (unsigned)vj * plane;             // absolute: the view's plane included
             const unsigned long long valid_m = __ballot(vj < nviews);
             unsigned long long out_m = __ballot(vj < nviews && box_out);
@@ -1096,9 +1115,10 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 #define F3D_FUSE_GRID (256 * 4 * 8)     // k_fuse: blocks per launch (multiple of 8; several rounds so that the tail stays short)
 #endif
 
-static size_t fuse_lds_bytes(int hist_dwords_per_point, int ppl) {   // k_fuse: tables + histogram of `ppl` points per lane
-    return (64 * F3D_CULL_ROW + 128 + 2 * F3D_VHEAD * 64) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
+static size_t fuse_lds_bytes(int hist_dwords_per_point, int ppl, bool tables = true) {   // k_fuse: [tables +] code book + histograms of `ppl` points per lane
+    return ((tables ? 64 * F3D_CULL_ROW + 2 * F3D_VHEAD * 64 : 0) + 128) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
 }
+size_t f3d_fuse_tables_bytes(int nviews) { return (size_t)((nviews + 63) / 64) * 64 * (24 * sizeof(float) + F3D_VHEAD * sizeof(double)); }
 
 size_t f3d_fuse_lds_bytes(int mode, int nclasses) {                 // LDS of k_fuse_exact
     const int ncols = nclasses + 1;
@@ -1155,34 +1175,40 @@ template <typename T, bool V>
 static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* views_dev, int nviews, const uint8_t* masks, const uint8_t* cmasks,
                                 int h, int w, int nclasses, const f3d_filter_args& flt, double threshold, int64_t* classes, uint16_t* votes,
                                 int* err, const int32_t* perm, bool gather_xyz, unsigned int* todo_count, int32_t* todo,
-                                unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, int mode, int grid, int grid1, hipStream_t s) {
+                                unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, void* tables, int mode, int grid, int grid1,
+                                hipStream_t s) {
     const bool fast = cmasks != nullptr;                     // no coded masks (nclasses > F3D_CODE_MAX_NCLASSES): exact kernel only
     if (fast && (n > 0x7ffff000LL || (flt.nfilter > 0 && !flt.cls_dev) || (uint64_t)nviews * f3d_coded_plane(h, w) >= (1ull << 32)))
         return hipErrorInvalidValue;                         // 32-bit point indices and mask offsets; filter list in device memory
     const dim3 g(grid), b(F3D_BLOCK), ge(fast ? 512 : grid);
     const int words_max = (nclasses + 1 + 2 + 3) >> 2;      // every label 0..nclasses present, plus the codes "no sample" and "rejected"
-    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2), lds_full = fuse_lds_bytes(words_max, 1);
+    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2), lds_full = fuse_lds_bytes(words_max, 1, false);
+    float* ctabT = reinterpret_cast<float*>(tables);
+    double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((nviews + 63) / 64) * 64 * 24 * sizeof(float));
     const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses);
     if (lds_exact > 160 * 1024 || lds_full > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e;
     if (fast) {
         const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
-        auto ks = k_fuse<T, 2, V, true, false>;              // dword bins: at most F3D_BIN32_MAX_CODES codes
-        auto km2 = wrap ? k_fuse<T, 2, V, false, true> : k_fuse<T, 2, V, false, false>;   // 8-bit bins, 4 per dword, 2 points per lane
-        auto kf = wrap ? k_fuse<T, 1, V, false, true> : k_fuse<T, 1, V, false, false>;    // any alphabet: 1 point per lane (LDS)
+        auto ks = k_fuse<T, 2, V, true, false, true>;        // dword bins: at most F3D_BIN32_MAX_CODES codes
+        auto km2 = wrap ? k_fuse<T, 2, V, false, true, true> : k_fuse<T, 2, V, false, false, true>;   // 8-bit bins, 4 per dword, 2 points per lane
+        auto kf = wrap ? k_fuse<T, 1, V, false, true, false> : k_fuse<T, 1, V, false, false, false>;  // any alphabet: 1 point per lane, tables in global memory
         if ((e = raise_lds(ks, lds_small)) != hipSuccess || (e = raise_lds(kf, lds_full)) != hipSuccess) return e;
         // three instances are enqueued (dword bins for tiny alphabets; packed 8-bit bins with LDS for up to F3D_PACKED_SMALL_WORDS
         // words, i.e. 48 codes; packed bins for any alphabet): LDS per block decides how many blocks a CU holds, and only the device
         // knows how many labels the masks contain -- the code book says which instance runs, the others return at once
         const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2);
         hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
-                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES);
+                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT);
         if (nclasses + 3 > F3D_BIN32_MAX_CODES)
             hipLaunchKernelGGL(km2, g, b, lds_mid, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
-                               classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS);
-        if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS)
+                               classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS, ctabT, vtabT);
+        if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS) {
+            hipLaunchKernelGGL(k_views_tables, dim3(8), b, 0, s, views_dev, nviews, ctabT, vtabT);
             hipLaunchKernelGGL(kf, dim3(grid1), b, lds_full, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev,
-                               threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 256);
+                               threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 256,
+                               ctabT, vtabT);
+        }
         // middle tier: the deferred points again, in float64; what it cannot prove either lands in the second list
         auto km = k_fuse_mid<T, V>;
         const size_t lds_tier2 = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
@@ -1207,8 +1233,8 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
                            double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
-                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, hipStream_t s) {
-    // todo_count points at 4 counters (first list, second list, 2 spare) followed by the two index lists of n entries each
+                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, void* tables, hipStream_t s) {
+    // tables: f3d_fuse_tables_bytes(nviews) of device scratch.  todo_count points at 4 counters (first list, second list, 2 spare) followed by the two index lists of n entries each
     if (n <= 0) return hipSuccess;
     unsigned int* todo2_count = todo_count + 1;
     int32_t* todo2 = todo + n;
@@ -1221,7 +1247,7 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
         hipError_t e0 = hipMemsetAsync(todo_count, 0, 4 * sizeof(unsigned int), s);
         if (e0 != hipSuccess) return e0;
     }
-#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, mode, grid, grid1, s
+#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, grid1, s
     if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true>(F3D_ARGS) : launch_fuse_t<double, false>(F3D_ARGS);
     return votes ? launch_fuse_t<float, true>(F3D_ARGS) : launch_fuse_t<float, false>(F3D_ARGS);
 #undef F3D_ARGS

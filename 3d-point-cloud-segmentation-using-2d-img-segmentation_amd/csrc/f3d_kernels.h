@@ -69,7 +69,9 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
                            double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
-                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, hipStream_t s);
+                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, void* tables /* f3d_fuse_tables_bytes(nviews) */,
+                           hipStream_t s);
+size_t f3d_fuse_tables_bytes(int nviews);
 // masks [V,H,W] row-major labels -> 8x8-pixel tiles of vote-bin codes (any H, W); dst holds f3d_coded_masks_bytes()
 size_t f3d_coded_masks_bytes(int nviews, int h, int w);
 // (builds the code book `cb` first: from filter_classes when it is short and no vote rows are wanted, else from the labels present)
