@@ -24,7 +24,7 @@ namespace {
 
 enum { SLOT_XYZ = 0, SLOT_OUT0, SLOT_OUT1, SLOT_VIEWS, SLOT_MASKS, SLOT_AUX0, SLOT_AUX1, SLOT_SORT_PERM, SLOT_SORT_SCRATCH,
        SLOT_TILED_MASKS, SLOT_TODO, SLOT_GRAPH, SLOT_GRAPH_BBOX, SLOT_PATCH,
-       SLOT_GRP_ORDER, SLOT_GRP_KEYS, SLOT_GRP_STARTS, SLOT_GRP_SCRATCH, SLOT_OBB_TABLE, SLOT_OBB_FACETS, SLOT_OBB_CAND, SLOT_FUSE_TABLES, SLOT_COUNT };
+       SLOT_GRP_ORDER, SLOT_GRP_KEYS, SLOT_GRP_STARTS, SLOT_GRP_SCRATCH, SLOT_OBB_TABLE, SLOT_OBB_FACETS, SLOT_OBB_CAND, SLOT_FUSE_TABLES, SLOT_FUSE_CARRY, SLOT_FUSE_XYZ, SLOT_COUNT };
 
 thread_local char g_create_err[512] = "";
 
@@ -56,6 +56,8 @@ struct f3d_ctx {
     // instance grouping of the last f3d_group_by_id call (host-pointer sequence group -> extremes -> hull filter)
     int64_t grp_n, grp_nids;
     int grp_dtype;
+    // view-chunked fused call in progress (f3d_fuse_chunked_begin_dev .. the chunk with v_end == nviews)
+    struct { int active, next, nviews, h, w, nclasses, gather; int64_t n; const int32_t* perm; const void* xyz; } chunk;
 };
 
 namespace {
@@ -562,7 +564,95 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
     void* tables;                                                                               // grows on first use only
     if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews > 0 ? nviews : 1), &tables))) return rc;
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,
-                                 ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), ctx->codebook, tables, s));
+                                 ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), ctx->codebook, tables,
+                                 0, nviews, nullptr, nullptr, s));
+    return F3D_OK;
+}
+
+// ---- the same path with the views arriving in chunks (multi-GPU: the masks of chunk c+1 are still in flight while chunk c votes)
+int f3d_mask_presence_dev(f3d_ctx* ctx, const uint8_t* masks, int nviews, int h, int w, uint8_t* present256, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (nviews < 0 || h <= 0 || w <= 0 || !present256 || (nviews > 0 && !masks)) return fail(ctx, F3D_ERR_INVALID, "mask_presence: bad arguments");
+    hipStream_t s = pick(ctx, stream);
+    F3D_HIP(ctx, f3d_launch_mask_presence(masks, (int64_t)nviews * h * w, ctx->codebook, s));
+    F3D_HIP(ctx, f3d_launch_presence_bytes(ctx->codebook, present256, true, s));
+    return F3D_OK;
+}
+
+int f3d_fuse_chunked_begin_dev(f3d_ctx* ctx, const uint8_t* present256, int64_t n, int nviews, int h, int w, int nclasses,
+                               const int32_t* filter, int nfilter, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    ctx->chunk.active = 0;
+    if (n < 0 || n > 0x7ffff000LL || nviews <= 0 || nviews > 255 || h <= 0 || w <= 0 || nclasses < 0 || nclasses > F3D_CODE_MAX_NCLASSES)
+        return fail(ctx, F3D_ERR_INVALID, "fuse_chunked_begin: bad arguments (1..255 views, nclasses <= %d)", F3D_CODE_MAX_NCLASSES);
+    if (f3d_coded_masks_bytes(nviews, h, w) >= ((size_t)1 << 32))
+        return fail(ctx, F3D_ERR_INVALID, "fuse_chunked_begin: %d coded masks of %d x %d exceed 4 GiB; use f3d_project_vote_argmax_dev", nviews, h, w);
+    hipStream_t s = pick(ctx, stream);
+    f3d_filter_args fa;
+    if ((rc = make_filter(ctx, filter, nfilter, nclasses + 1, true, s, &fa))) return rc;
+    void* p;                                                   // every scratch buffer of the chunk calls: they allocate nothing
+    if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &p))) return rc;
+    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &p))) return rc;
+    if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews), &p))) return rc;
+    if ((rc = ensure(ctx, SLOT_FUSE_CARRY, f3d_fuse_carry_bytes(n, nclasses), &p))) return rc;
+    if (n > 0) {                                               // F3D_FUSE_SORT / a gathered cloud: permutation, sort scratch, cell-order copy
+        if ((rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &p))) return rc;
+        if ((rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &p))) return rc;
+        if ((rc = ensure(ctx, SLOT_FUSE_XYZ, (size_t)n * 24, &p))) return rc;
+    }
+    if (present256) F3D_HIP(ctx, f3d_launch_presence_bytes(ctx->codebook, const_cast<uint8_t*>(present256), false, s));
+    else F3D_HIP(ctx, hipMemsetAsync(ctx->codebook->presence, 0xFF, sizeof ctx->codebook->presence, s));     // every label gets a bin
+    F3D_HIP(ctx, f3d_launch_code_book(ctx->codebook, nclasses, fa, false, s));
+    ctx->chunk.active = 1; ctx->chunk.next = 0; ctx->chunk.nviews = nviews; ctx->chunk.h = h; ctx->chunk.w = w;
+    ctx->chunk.nclasses = nclasses; ctx->chunk.n = n; ctx->chunk.perm = nullptr; ctx->chunk.gather = 0; ctx->chunk.xyz = nullptr;
+    return F3D_OK;
+}
+
+int f3d_fuse_chunk_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews, int v_begin, int v_end,
+                       const uint8_t* masks, int h, int w, int nclasses, const int32_t* filter, int nfilter, double threshold,
+                       int64_t* classes, unsigned flags, const int32_t* perm, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (!ctx->chunk.active || ctx->chunk.next != v_begin || ctx->chunk.nviews != nviews || ctx->chunk.h != h || ctx->chunk.w != w ||
+        ctx->chunk.nclasses != nclasses || ctx->chunk.n != n || v_end <= v_begin || v_end > nviews)
+        return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: views [%d, %d) do not continue the call begun with f3d_fuse_chunked_begin_dev "
+                    "(next view %d of %d, same n / h / w / nclasses required)", v_begin, v_end, ctx->chunk.active ? ctx->chunk.next : -1, ctx->chunk.nviews);
+    if (!classes || (n > 0 && !xyz) || !views_dev || !masks) return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: bad arguments");
+    if ((flags & F3D_FUSE_SORT) && perm) return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: F3D_FUSE_SORT and perm are exclusive");
+    hipStream_t s = pick(ctx, stream);
+    f3d_filter_args fa;
+    if ((rc = make_filter(ctx, filter, nfilter, nclasses + 1, true, s, &fa))) return rc;
+    if (v_begin == 0) {                                        // the point order is fixed by the first chunk
+        ctx->chunk.perm = perm; ctx->chunk.gather = ((flags & F3D_FUSE_GATHER) && perm) ? 1 : 0;
+        if ((flags & F3D_FUSE_SORT) && n > 512) {
+            void *sperm, *scratch;
+            if ((rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &sperm))) return rc;
+            if ((rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &scratch))) return rc;
+            F3D_HIP(ctx, f3d_launch_cell_sort(xyz, dtype, n, nullptr, (int32_t*)sperm, scratch, s));
+            ctx->chunk.perm = (const int32_t*)sperm; ctx->chunk.gather = 1;
+        }
+        ctx->chunk.xyz = xyz;
+    }
+    // a cloud read through a permutation and more chunks to come: the first chunk leaves it behind in cell order (context scratch),
+    // the later chunks stream that copy instead of gathering 24-byte points again
+    void* keep = nullptr;
+    if (v_begin == 0 && v_end < nviews && ctx->chunk.gather && n > 0) {
+        if ((rc = ensure(ctx, SLOT_FUSE_XYZ, (size_t)n * 3 * (dtype == F3D_F64 ? 8 : 4), &keep))) return rc;
+    }
+    const void* cxyz = ctx->chunk.xyz;
+    const bool cgather = ctx->chunk.gather != 0;
+    void *tm, *todo, *tables, *carry;
+    if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &tm))) return rc;
+    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
+    if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews), &tables))) return rc;
+    if ((rc = ensure(ctx, SLOT_FUSE_CARRY, f3d_fuse_carry_bytes(n, nclasses), &carry))) return rc;
+    const size_t plane = f3d_coded_masks_bytes(1, h, w);
+    F3D_HIP(ctx, f3d_launch_code_planes(masks + (size_t)v_begin * h * w, (uint8_t*)tm + (size_t)v_begin * plane, v_end - v_begin, h, w, ctx->codebook, s));
+    F3D_HIP(ctx, f3d_launch_fuse(cxyz, dtype, n, views_dev, nviews, masks, (const uint8_t*)tm, h, w, nclasses, fa, threshold, classes, nullptr,
+                                 ctx->dev_err, ctx->chunk.perm, cgather, (unsigned int*)todo, (int32_t*)((char*)todo + 16),
+                                 ctx->codebook, tables, v_begin, v_end, (uint32_t*)carry, keep, s));
+    if (keep) { ctx->chunk.xyz = keep; ctx->chunk.gather = 0; }
+    ctx->chunk.next = v_end;
+    if (v_end == nviews) ctx->chunk.active = 0;
     return F3D_OK;
 }
 

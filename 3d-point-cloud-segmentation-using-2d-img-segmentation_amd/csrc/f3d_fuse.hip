@@ -176,6 +176,14 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_mask_presence(const uint8_t* __re
     }
 }
 
+// the presence set as 256 bytes of 0 / 1 (to_bytes) or back (one block of 256 threads)
+__global__ __launch_bounds__(F3D_BLOCK) void k_presence_bytes(f3d_codebook* __restrict__ cb, uint8_t* __restrict__ bytes256, int to_bytes) {
+    const unsigned l = threadIdx.x;
+    if (to_bytes) { bytes256[l] = (uint8_t)((cb->presence[l >> 5] >> (l & 31u)) & 1u); return; }
+    const unsigned long long m = __ballot(bytes256[l] != 0);
+    if ((l & 63u) == 0u) { cb->presence[l >> 5] = (unsigned)m; cb->presence[(l >> 5) + 1] = (unsigned)(m >> 32); }
+}
+
 // one block of 256 threads: thread l decides the code of label l.  book: 0 = every label 0..nclasses has a bin (no
 // presence pass ran), 1 = presence book, 2 = filter book.
 __global__ __launch_bounds__(F3D_BLOCK) void k_code_lut(f3d_codebook* __restrict__ cb, int nclasses, int book, f3d_filter_args flt) {
@@ -620,7 +628,12 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_views_tables(const f3d_view* __re
     }
 }
 
-template <typename T, int PPL, bool WRITE_VOTES, bool BIN32, bool WRAP, bool TLDS>
+// CARRY: the instance of the view-chunked call (f3d_fuse_chunk_dev): the views arrive in several launches; between two of them a
+// point's vote bins live in HBM as `carry` [tile][point slot][word][F3D_BLOCK], 8-bit bins packed four to a dword whatever the LDS
+// form (at most 255 views in total: no bin can wrap); byte 0 of word 0 -- the "no sample" bin nothing reads -- carries the point's
+// "deferred" flag.  chunk_flags bit 0: load the carry (not the first chunk), bit 1: store it instead of finishing (not the last).
+// xyz_keep (first chunk of a cloud read through perm): the points are written back in cell order for the chunks that follow.
+template <typename T, int PPL, bool WRITE_VOTES, bool BIN32, bool WRAP, bool TLDS, bool CARRY>
 __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __restrict__ xyz, int64_t n,
                                                      const f3d_view* __restrict__ views, int nviews,
                                                      const uint8_t* __restrict__ cmasks, int H, int W,
@@ -629,7 +642,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                                                      int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
                                                      unsigned int* __restrict__ todo_count, int32_t* __restrict__ todo,
                                                      const f3d_codebook* __restrict__ cb, int cmin, int cmax,
-                                                     const float* __restrict__ ctabT, const double* __restrict__ vtabT) {
+                                                     const float* __restrict__ ctabT, const double* __restrict__ vtabT,
+                                                     uint32_t* __restrict__ carry, int chunk_flags, T* __restrict__ xyz_keep) {
     const int ncodes = cb->ncodes;                                        // wave-uniform: scalar load
     if (ncodes > cmax || ncodes < cmin) return;                           // the other instance's book
     const int words = (ncodes + 3) >> 2;
@@ -695,6 +709,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 orig[q] = live[q] ? (perm ? perm[i] : i) : i;                      // caller-order index of this point
                 p[q].x = p[q].y = p[q].z = 0.0;
                 if (live[q]) p[q] = load_point(xyz, (int64_t)(gather_xyz ? orig[q] : i));
+                // first of several view chunks of a gathered cloud: leave the points behind in cell order, the later chunks stream them
+                if (CARRY && xyz_keep && live[q]) { xyz_keep[3 * (size_t)i] = (T)p[q].x; xyz_keep[3 * (size_t)i + 1] = (T)p[q].y; xyz_keep[3 * (size_t)i + 2] = (T)p[q].z; }
                 const double pscale = (fabs(p[q].x) + fabs(p[q].y)) + fabs(p[q].z);
                 act[q] = live[q] & (pscale < 1.0e30);          // float32 work is meaningful (no overflow, no NaN)
                 defer[q] = live[q] & !act[q];                  // this point goes to the next tier
@@ -718,7 +734,25 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             DY = (f32x2){(float)(p[0].y - (double)c1), (float)(p[1].y - (double)c1)};
             DZ = (f32x2){(float)(p[0].z - (double)c2), (float)(p[1].z - (double)c2)};
         }
-        for (int wd = 0; wd < hdw; ++wd) { hcol0[wd * F3D_BLOCK] = 0u; if (PPL == 2) hcol1[wd * F3D_BLOCK] = 0u; }   // own columns only: no barrier
+        if (CARRY && (chunk_flags & 1)) {                                   // the bins (and the deferred flag) of the earlier view chunks
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                uint32_t* hc = q ? hcol1 : hcol0;
+                const uint32_t* cq = carry + ((size_t)(tile * PPL + q) * words) * F3D_BLOCK + tid;
+                for (int wd = 0; wd < words; ++wd) {
+                    uint32_t x = cq[wd * F3D_BLOCK];
+                    if (wd == 0) { defer[q] = defer[q] | (live[q] & ((x & 0xFFu) != 0u)); x &= ~0xFFu; }
+                    if (BIN32) {
+#pragma unroll
+                        for (int b4 = 0; b4 < 4; ++b4) if (4 * wd + b4 < ncodes) hc[(4 * wd + b4) * F3D_BLOCK] = (x >> (8 * b4)) & 0xFFu;
+                    } else {
+                        hc[wd * F3D_BLOCK] = x;
+                    }
+                }
+            }
+        } else {
+            for (int wd = 0; wd < hdw; ++wd) { hcol0[wd * F3D_BLOCK] = 0u; if (PPL == 2) hcol1[wd * F3D_BLOCK] = 0u; }   // own columns only: no barrier
+        }
         unsigned nvalid[2] = {0u, 0u};
         unsigned pend[2] = {F3D_CODE_NONE, F3D_CODE_NONE};   // software-pipelined gathers: a code is voted one view (chunk) later
         unsigned ccode[2][F3D_CHUNK];
@@ -853,6 +887,21 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
         for (int q = 0; q < PPL; ++q) {
             vote(q, pend[q]);
             uint32_t* hc = q ? hcol1 : hcol0;
+            if (CARRY && (chunk_flags & 2)) {                                 // more views to come: park the bins in HBM
+                uint32_t* cq = carry + ((size_t)(tile * PPL + q) * words) * F3D_BLOCK + tid;
+                for (int wd = 0; wd < words; ++wd) {
+                    uint32_t x = 0u;
+                    if (BIN32) {
+#pragma unroll
+                        for (int b4 = 0; b4 < 4; ++b4) if (4 * wd + b4 < ncodes) x |= hc[(4 * wd + b4) * F3D_BLOCK] << (8 * b4);
+                    } else {
+                        x = hc[wd * F3D_BLOCK];
+                    }
+                    if (wd == 0) x = (x & ~0xFFu) | (defer[q] ? 1u : 0u);
+                    cq[wd * F3D_BLOCK] = x;
+                }
+                continue;
+            }
             bool bad = false, trusted = true;
             if (BIN32) finish_bin32<WRITE_VOTES>(hc, ncodes, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q], classes, votes_out, bad);
             else trusted = finish_coded<WRITE_VOTES, WRAP>(nvalid[q], hc, words, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q],
@@ -1118,6 +1167,10 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 static size_t fuse_lds_bytes(int hist_dwords_per_point, int ppl, bool tables = true) {   // k_fuse: [tables +] code book + histograms of `ppl` points per lane
     return ((tables ? 64 * F3D_CULL_ROW + 2 * F3D_VHEAD * 64 : 0) + 128) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
 }
+size_t f3d_fuse_carry_bytes(int64_t n, int nclasses) {     // packed bins of every point slot of the 256- or 512-point tiles
+    const size_t words_max = (size_t)((nclasses + 1 + 2 + 3) >> 2);
+    return (size_t)((n + 2 * F3D_BLOCK - 1) / (2 * F3D_BLOCK)) * 2 * F3D_BLOCK * words_max * sizeof(uint32_t);
+}
 size_t f3d_fuse_tables_bytes(int nviews) { return (size_t)((nviews + 63) / 64) * 64 * (24 * sizeof(float) + F3D_VHEAD * sizeof(double)); }
 
 size_t f3d_fuse_lds_bytes(int mode, int nclasses) {                 // LDS of k_fuse_exact
@@ -1133,12 +1186,9 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
 
 size_t f3d_coded_masks_bytes(int nviews, int h, int w) { return (size_t)nviews * f3d_coded_plane(h, w); }
 
-hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, const f3d_filter_args& flt,
-                                 bool want_votes, f3d_codebook* cb, hipStream_t s) {
-    if (nviews <= 0) return hipSuccess;
-    if (nclasses < 0 || nclasses > F3D_CODE_MAX_NCLASSES || ((uintptr_t)dst & 7)) return hipErrorInvalidValue;
-    // which book: the filter's own labels when there are few of them (nothing else is ever looked at, voting.py:121-124);
-    // otherwise the labels that occur in the masks
+// which book: the filter's own labels when there are few of them (nothing else is ever looked at, voting.py:121-124);
+// otherwise the labels that occur in the masks
+static int pick_book(const f3d_filter_args& flt, bool want_votes) {
     int distinct = 0;
     if (flt.nfilter > 0 && flt.nfilter <= 8 && !want_votes) {
         for (int k = 0; k < flt.nfilter; ++k) {
@@ -1147,22 +1197,52 @@ hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, i
             distinct += seen ? 0 : 1;
         }
     }
-    const int book = (distinct > 0) ? 2 : 1;
-    const int64_t nbytes = (int64_t)nviews * h * w;
-    if (book == 1) {
-        hipError_t e = hipMemsetAsync(cb->presence, 0, sizeof cb->presence, s);
-        if (e != hipSuccess) return e;
-        const bool vec = !((uintptr_t)src & 7);
-        const dim3 g(grid_for(nbytes >> 3, F3D_BLOCK, 256 * 8)), b(F3D_BLOCK);
-        if (vec) hipLaunchKernelGGL(k_mask_presence<true>, g, b, 0, s, src, nbytes, cb);
-        else hipLaunchKernelGGL(k_mask_presence<false>, g, b, 0, s, src, nbytes, cb);
-    }
-    hipLaunchKernelGGL(k_code_lut, dim3(1), dim3(F3D_BLOCK), 0, s, cb, nclasses, book, flt);
+    return (distinct > 0) ? 2 : 1;
+}
+
+// labels present in `nbytes` mask bytes -> cb->presence (replaced, not accumulated)
+hipError_t f3d_launch_mask_presence(const uint8_t* src, int64_t nbytes, f3d_codebook* cb, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(cb->presence, 0, sizeof cb->presence, s);
+    if (e != hipSuccess || nbytes <= 0) return e;
+    const bool vec = !((uintptr_t)src & 7);
+    const dim3 g(grid_for(nbytes >> 3, F3D_BLOCK, 256 * 8)), b(F3D_BLOCK);
+    if (vec) hipLaunchKernelGGL(k_mask_presence<true>, g, b, 0, s, src, nbytes, cb);
+    else hipLaunchKernelGGL(k_mask_presence<false>, g, b, 0, s, src, nbytes, cb);
+    return hipGetLastError();
+}
+
+// cb->presence <-> 256 bytes of 0 / 1 (the form ranks can combine with an all-reduce MAX: RCCL has no bitwise OR)
+hipError_t f3d_launch_presence_bytes(f3d_codebook* cb, uint8_t* bytes256, bool to_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(k_presence_bytes, dim3(1), dim3(F3D_BLOCK), 0, s, cb, bytes256, to_bytes ? 1 : 0);
+    return hipGetLastError();
+}
+
+// the code book from cb->presence (presence book) or from the filter list (filter book)
+hipError_t f3d_launch_code_book(f3d_codebook* cb, int nclasses, const f3d_filter_args& flt, bool want_votes, hipStream_t s) {
+    if (nclasses < 0 || nclasses > F3D_CODE_MAX_NCLASSES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_code_lut, dim3(1), dim3(F3D_BLOCK), 0, s, cb, nclasses, pick_book(flt, want_votes), flt);
+    return hipGetLastError();
+}
+
+// `nviews` planes of src -> coded, bordered, tiled planes at dst, with the book as it stands
+hipError_t f3d_launch_code_planes(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, const f3d_codebook* cb, hipStream_t s) {
+    if (nviews <= 0) return hipSuccess;
+    if ((uintptr_t)dst & 7) return hipErrorInvalidValue;
     const int64_t total = (int64_t)nviews * (int64_t)(f3d_coded_plane(h, w) / 8);
     const dim3 g(grid_for(total, F3D_BLOCK, F3D_GRID_CAP)), b(F3D_BLOCK);
     if (!(w & 7) && !((uintptr_t)src & 7)) hipLaunchKernelGGL(k_code_masks<true>, g, b, 0, s, src, dst, nviews, h, w, cb);
     else hipLaunchKernelGGL(k_code_masks<false>, g, b, 0, s, src, dst, nviews, h, w, cb);
     return hipGetLastError();
+}
+
+hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, const f3d_filter_args& flt,
+                                 bool want_votes, f3d_codebook* cb, hipStream_t s) {
+    if (nviews <= 0) return hipSuccess;
+    if (nclasses < 0 || nclasses > F3D_CODE_MAX_NCLASSES || ((uintptr_t)dst & 7)) return hipErrorInvalidValue;
+    hipError_t e;
+    if (pick_book(flt, want_votes) == 1 && (e = f3d_launch_mask_presence(src, (int64_t)nviews * h * w, cb, s)) != hipSuccess) return e;
+    if ((e = f3d_launch_code_book(cb, nclasses, flt, want_votes, s)) != hipSuccess) return e;
+    return f3d_launch_code_planes(src, dst, nviews, h, w, cb, s);
 }
 
 template <typename KernelT>
@@ -1171,44 +1251,55 @@ static hipError_t raise_lds(KernelT kernel, size_t lds) {
     return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <typename T, bool V>
+template <typename T, bool V, bool CARRY>
 static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* views_dev, int nviews, const uint8_t* masks, const uint8_t* cmasks,
                                 int h, int w, int nclasses, const f3d_filter_args& flt, double threshold, int64_t* classes, uint16_t* votes,
                                 int* err, const int32_t* perm, bool gather_xyz, unsigned int* todo_count, int32_t* todo,
                                 unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, void* tables, int mode, int grid, int grid1,
-                                hipStream_t s) {
+                                int v0, int v1, uint32_t* carry, void* xyz_keep, hipStream_t s) {
+    // CARRY: the fast kernel runs over the views [v0, v1) only and parks / resumes the vote bins in `carry`; the float64 tier and
+    // the exact kernel follow the last chunk (v1 == nviews) and see every view.  Otherwise v0 = 0, v1 = nviews.
     const bool fast = cmasks != nullptr;                     // no coded masks (nclasses > F3D_CODE_MAX_NCLASSES): exact kernel only
+    if (CARRY && (!fast || nviews > 255 || !carry || v0 < 0 || v1 <= v0 || v1 > nviews)) return hipErrorInvalidValue;
+    const int chunk_flags = CARRY ? ((v0 > 0 ? 1 : 0) | (v1 < nviews ? 2 : 0)) : 0;
+    const f3d_view* cviews = views_dev + v0;
+    const uint8_t* ccm = fast ? cmasks + (size_t)v0 * f3d_coded_plane(h, w) : nullptr;
+    const int cnv = v1 - v0;
     if (fast && (n > 0x7ffff000LL || (flt.nfilter > 0 && !flt.cls_dev) || (uint64_t)nviews * f3d_coded_plane(h, w) >= (1ull << 32)))
         return hipErrorInvalidValue;                         // 32-bit point indices and mask offsets; filter list in device memory
     const dim3 g(grid), b(F3D_BLOCK), ge(fast ? 512 : grid);
     const int words_max = (nclasses + 1 + 2 + 3) >> 2;      // every label 0..nclasses present, plus the codes "no sample" and "rejected"
     const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2), lds_full = fuse_lds_bytes(words_max, 1, false);
     float* ctabT = reinterpret_cast<float*>(tables);
-    double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((nviews + 63) / 64) * 64 * 24 * sizeof(float));
+    double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((cnv + 63) / 64) * 64 * 24 * sizeof(float));
     const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses);
     if (lds_exact > 160 * 1024 || lds_full > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e;
     if (fast) {
         const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
-        auto ks = k_fuse<T, 2, V, true, false, true>;        // dword bins: at most F3D_BIN32_MAX_CODES codes
-        auto km2 = wrap ? k_fuse<T, 2, V, false, true, true> : k_fuse<T, 2, V, false, false, true>;   // 8-bit bins, 4 per dword, 2 points per lane
-        auto kf = wrap ? k_fuse<T, 1, V, false, true, false> : k_fuse<T, 1, V, false, false, false>;  // any alphabet: 1 point per lane, tables in global memory
+        auto ks = k_fuse<T, 2, V, true, false, true, CARRY>;     // dword bins: at most F3D_BIN32_MAX_CODES codes
+        // 8-bit bins, 4 per dword, 2 points per lane;  any alphabet: 1 point per lane, tables in global memory
+        auto km2 = k_fuse<T, 2, V, false, false, true, CARRY>;
+        auto kf = k_fuse<T, 1, V, false, false, false, CARRY>;
+        if (!CARRY && wrap) { km2 = k_fuse<T, 2, V, false, true, true, false>; kf = k_fuse<T, 1, V, false, true, false, false>; }
         if ((e = raise_lds(ks, lds_small)) != hipSuccess || (e = raise_lds(kf, lds_full)) != hipSuccess) return e;
         // three instances are enqueued (dword bins for tiny alphabets; packed 8-bit bins with LDS for up to F3D_PACKED_SMALL_WORDS
         // words, i.e. 48 codes; packed bins for any alphabet): LDS per block decides how many blocks a CU holds, and only the device
         // knows how many labels the masks contain -- the code book says which instance runs, the others return at once
         const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2);
-        hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
-                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT);
+        hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
+                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
         if (nclasses + 3 > F3D_BIN32_MAX_CODES)
-            hipLaunchKernelGGL(km2, g, b, lds_mid, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
-                               classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS, ctabT, vtabT);
+            hipLaunchKernelGGL(km2, g, b, lds_mid, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
+                               classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS,
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
         if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS) {
-            hipLaunchKernelGGL(k_views_tables, dim3(8), b, 0, s, views_dev, nviews, ctabT, vtabT);
-            hipLaunchKernelGGL(kf, dim3(grid1), b, lds_full, s, (const T*)xyz, n, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter, flt.cls_dev,
+            hipLaunchKernelGGL(k_views_tables, dim3(8), b, 0, s, cviews, cnv, ctabT, vtabT);
+            hipLaunchKernelGGL(kf, dim3(grid1), b, lds_full, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev,
                                threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 256,
-                               ctabT, vtabT);
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
         }
+        if (chunk_flags & 2) return hipGetLastError();       // more view chunks to come
         // middle tier: the deferred points again, in float64; what it cannot prove either lands in the second list
         auto km = k_fuse_mid<T, V>;
         const size_t lds_tier2 = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
@@ -1233,7 +1324,12 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
                            double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
-                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, void* tables, hipStream_t s) {
+                           unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, void* tables, int v0, int v1, uint32_t* carry,
+                           void* xyz_keep, hipStream_t s) {
+    // carry == NULL: one launch over all views (v0, v1 ignored).  Otherwise the views [v0, v1) of a view-chunked call: `carry` holds
+    // f3d_fuse_carry_bytes(n, nclasses) of device scratch that must survive from the chunk with v0 == 0 to the one with v1 == nviews;
+    // chunks in ascending order without gaps; no vote output.  xyz_keep (may be NULL; first chunk with gather_xyz only): n points of
+    // xyz's type, receives the cloud in perm order -- the caller passes it as xyz (gather_xyz = false, same perm) from then on.
     // tables: f3d_fuse_tables_bytes(nviews) of device scratch.  todo_count points at 4 counters (first list, second list, 2 spare) followed by the two index lists of n entries each
     if (n <= 0) return hipSuccess;
     unsigned int* todo2_count = todo_count + 1;
@@ -1243,13 +1339,16 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     const int64_t ntiles1 = (n + F3D_BLOCK - 1) / F3D_BLOCK;                   // ... 1 in the any-alphabet instance
     int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID), grid1 = (int)(ntiles1 < F3D_FUSE_GRID ? ntiles1 : F3D_FUSE_GRID);
     grid = (grid + 7) & ~7; grid1 = (grid1 + 7) & ~7;        // the XCD-aware tile mapping needs a multiple of 8 blocks
-    if (cmasks) {
+    if (carry && votes) return hipErrorInvalidValue;
+    if (!carry) { v0 = 0; v1 = nviews; }
+    if (cmasks && v0 == 0) {
         hipError_t e0 = hipMemsetAsync(todo_count, 0, 4 * sizeof(unsigned int), s);
         if (e0 != hipSuccess) return e0;
     }
-#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, grid1, s
-    if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true>(F3D_ARGS) : launch_fuse_t<double, false>(F3D_ARGS);
-    return votes ? launch_fuse_t<float, true>(F3D_ARGS) : launch_fuse_t<float, false>(F3D_ARGS);
+#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, grid1, v0, v1, carry, xyz_keep, s
+    if (carry) return dtype == F3D_F64 ? launch_fuse_t<double, false, true>(F3D_ARGS) : launch_fuse_t<float, false, true>(F3D_ARGS);
+    if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true, false>(F3D_ARGS) : launch_fuse_t<double, false, false>(F3D_ARGS);
+    return votes ? launch_fuse_t<float, true, false>(F3D_ARGS) : launch_fuse_t<float, false, false>(F3D_ARGS);
 #undef F3D_ARGS
 }
 

@@ -70,8 +70,13 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
                            const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
                            double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,
                            unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, void* tables /* f3d_fuse_tables_bytes(nviews) */,
-                           hipStream_t s);
+                           int v0, int v1, uint32_t* carry /* NULL: all views in one launch */, void* xyz_keep, hipStream_t s);
 size_t f3d_fuse_tables_bytes(int nviews);
+size_t f3d_fuse_carry_bytes(int64_t n, int nclasses);
+hipError_t f3d_launch_mask_presence(const uint8_t* src, int64_t nbytes, f3d_codebook* cb, hipStream_t s);
+hipError_t f3d_launch_presence_bytes(f3d_codebook* cb, uint8_t* bytes256, bool to_bytes, hipStream_t s);
+hipError_t f3d_launch_code_book(f3d_codebook* cb, int nclasses, const f3d_filter_args& flt, bool want_votes, hipStream_t s);
+hipError_t f3d_launch_code_planes(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, const f3d_codebook* cb, hipStream_t s);
 // masks [V,H,W] row-major labels -> 8x8-pixel tiles of vote-bin codes (any H, W); dst holds f3d_coded_masks_bytes()
 size_t f3d_coded_masks_bytes(int nviews, int h, int w);
 // (builds the code book `cb` first: from filter_classes when it is short and no vote rows are wanted, else from the labels present)

@@ -82,6 +82,9 @@ def library():
         'f3d_project_view_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, vp]),
         'f3d_project_vote_argmax': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp]),
         'f3d_project_vote_argmax_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, i32, i32, i32, vp, i32, dbl, vp, vp, C.c_uint, vp, vp]),
+        'f3d_mask_presence_dev': (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        'f3d_fuse_chunked_begin_dev': (i32, [vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
+        'f3d_fuse_chunk_dev': (i32, [vp, vp, i32, i64, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, dbl, vp, C.c_uint, vp, vp]),
         'f3d_debug_fastpath_audit': (i32, [vp, vp, i32, i64, vp, i32, i32, i32, vp]),
         'f3d_debug_fuse_deferred': (i32, [vp, vp, vp]),
         'f3d_cloud_sort_cells_dev': (i32, [vp, vp, i32, i64, vp, vp, vp]),
@@ -564,6 +567,20 @@ class Context:
         self._check(self._lib.f3d_project_vote_argmax_dev(self._h, xyz_ptr, dtype, n, views_ptr, nviews, masks_ptr, h, w,
                                                           int(nclasses), _ptr(f), nf, float(threshold), classes_ptr,
                                                           votes_ptr, int(flags), perm_ptr, stream))
+
+    # the fused path with the views arriving in chunks (f3d.h: f3d_mask_presence_dev .. f3d_fuse_chunk_dev)
+    def mask_presence_dev(self, masks_ptr, nviews, h, w, present256_ptr, stream=None):
+        self._check(self._lib.f3d_mask_presence_dev(self._h, masks_ptr, nviews, h, w, present256_ptr, stream))
+
+    def fuse_chunked_begin_dev(self, present256_ptr, n, nviews, h, w, nclasses, filter_classes, stream=None):
+        f, nf = _filter(filter_classes)
+        self._check(self._lib.f3d_fuse_chunked_begin_dev(self._h, present256_ptr, n, nviews, h, w, int(nclasses), _ptr(f), nf, stream))
+
+    def fuse_chunk_dev(self, xyz_ptr, dtype, n, views_ptr, nviews, v_begin, v_end, masks_ptr, h, w, nclasses, threshold,
+                       filter_classes, classes_ptr, stream=None, flags=0, perm_ptr=None):
+        f, nf = _filter(filter_classes)
+        self._check(self._lib.f3d_fuse_chunk_dev(self._h, xyz_ptr, dtype, n, views_ptr, nviews, int(v_begin), int(v_end), masks_ptr, h, w,
+                                                 int(nclasses), _ptr(f), nf, float(threshold), classes_ptr, int(flags), perm_ptr, stream))
 
     def cloud_sort_cells_dev(self, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream=None):
         self._check(self._lib.f3d_cloud_sort_cells_dev(self._h, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream))

@@ -75,3 +75,84 @@ def sharded_cooccurrence(dist, local):
     t = torch.from_numpy(arr.astype(np.int32)).to(dev)          # gloo has no MAX for uint8
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.cpu().numpy().astype(np.uint8)
+
+
+# ---- within-step overlap: the mask all-gather split into view chunks, chunk c+1 in flight while chunk c votes --------------
+def chunk_layout(nviews, world, nchunks):
+    """(views per rank and chunk, view index of every plane of the chunked gather buffer).
+
+    Rank r owns the masks of views [r*per, (r+1)*per) and sends them in `nchunks` equal slices; collective c gathers slice c of
+    every rank, so the buffer holds chunk after chunk, inside a chunk rank after rank.  Votes are a sum over views, hence the
+    labels do not depend on this order -- only the view records have to be handed over in the same one."""
+    if nviews % world or (nviews // world) % nchunks:
+        raise ValueError(f'{nviews} views do not split into {world} ranks x {nchunks} equal chunks')
+    per = nviews // world
+    vc = per // nchunks
+    order = np.array([r * per + c * vc + k for c in range(nchunks) for r in range(world) for k in range(vc)], dtype=np.int64)
+    return vc, order
+
+
+class HipChunkEngine:
+    """The fused path of one rank behind `overlapped_labels`: device pointers into f3d's view-chunked entry points."""
+
+    def __init__(self, ctx, xyz, dtype, n, views_in_chunk_order, h, w, nclasses, threshold, filter_classes, classes, flags=0, perm_ptr=None):
+        import torch
+        self.ctx, self.xyz, self.dtype, self.n, self.views = ctx, xyz, dtype, n, views_in_chunk_order
+        self.h, self.w, self.nclasses, self.threshold, self.flt = h, w, nclasses, threshold, filter_classes
+        self.classes, self.flags, self.perm_ptr = classes, flags, perm_ptr
+        self.present = torch.empty(256, dtype=torch.uint8, device=xyz.device)
+
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream(self.xyz.device).cuda_stream
+
+    def presence(self, mask_shard):
+        self.ctx.mask_presence_dev(mask_shard.data_ptr(), mask_shard.shape[0], self.h, self.w, self.present.data_ptr(), self._stream())
+        return self.present
+
+    def begin(self, present):
+        self.ctx.fuse_chunked_begin_dev(None if present is None else present.data_ptr(), self.n, len(self.views), self.h, self.w,
+                                        self.nclasses, self.flt, self._stream())
+
+    def chunk(self, v_begin, v_end, masks):
+        self.ctx.fuse_chunk_dev(self.xyz.data_ptr(), self.dtype, self.n, self.views.data_ptr(), len(self.views), v_begin, v_end,
+                                masks.data_ptr(), self.h, self.w, self.nclasses, self.threshold, self.flt, self.classes.data_ptr(),
+                                self._stream(), flags=self.flags, perm_ptr=self.perm_ptr)
+
+
+def overlapped_labels(dist, engine, mask_shard, gathered, nchunks):
+    """One N-rank step with the exchange overlapped INSIDE the step.
+
+    mask_shard: uint8 [V/world, H, W] (this rank's masks);  gathered: uint8 [V, H, W] buffer in `chunk_layout` order.
+    1. the labels present in the local masks, all-reduced (MAX) -> the same vote-bin code book on every rank;
+    2. `nchunks` asynchronous all-gathers, all enqueued at once (the backend runs them in order on its own stream);
+    3. as soon as chunk c has landed, every local point votes on its views (engine.chunk) while chunk c+1.. are on the wire.
+    The per-point vote state between chunks lives in the engine (f3d: packed 8-bit bins in HBM, see f3d_fuse_chunk_dev)."""
+    import torch
+    world = dist.get_world_size()
+    per = mask_shard.shape[0]
+    if per % nchunks:
+        raise ValueError(f'{per} masks per rank do not split into {nchunks} chunks')
+    vc = per // nchunks
+    plane = mask_shard[0].numel()
+    present = engine.presence(mask_shard)
+    pres_work = None
+    if present is not None:
+        pres32 = present.to(torch.int32)                            # gloo has no MAX for uint8
+        pres_work = dist.all_reduce(pres32, op=dist.ReduceOp.MAX, async_op=True)
+    flat, shard_flat = gathered.view(-1), mask_shard.contiguous().view(-1)
+    works = []
+    for c in range(nchunks):
+        out = flat[c * world * vc * plane:(c + 1) * world * vc * plane]
+        src = shard_flat[c * vc * plane:(c + 1) * vc * plane]
+        try:
+            works.append(dist.all_gather_into_tensor(out, src, async_op=True))
+        except (RuntimeError, NotImplementedError):                 # a backend without the flat form
+            works.append(dist.all_gather(list(out.view(world, -1).unbind(0)), src, async_op=True))
+    if pres_work is not None:
+        pres_work.wait()                                            # device backends: the current stream waits, the host does not
+        present.copy_(pres32.to(torch.uint8))
+    engine.begin(present)
+    for c in range(nchunks):
+        works[c].wait()
+        engine.chunk(c * world * vc, (c + 1) * world * vc, gathered)

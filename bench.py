@@ -41,6 +41,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--points', type=int, default=10_000_000, help='points of the cloud (C3/C4: 10M), sharded over the ranks; per rank with --weak')
     ap.add_argument('--weak', action='store_true', help='N > 1: every rank owns --points points of an N x larger cloud (weak scaling)')
+    ap.add_argument('--exchange', default='pipelined', choices=['pipelined', 'chunked'],
+                    help='N > 1: pipelined = the all-gather of step i+1 overlaps the kernels of step i (double-buffered masks); chunked = inside '
+                         'one step, the all-gather split into --chunks view chunks, chunk c+1 on the wire while chunk c votes')
+    ap.add_argument('--chunks', type=int, default=2, help='view chunks per rank of --exchange chunked')
     ap.add_argument('--no-merge', action='store_true', help='skip the C5 bbox-merge leg (50M points, 4096 instances)')
     ap.add_argument('--views', type=int, default=64)
     ap.add_argument('--size', type=int, default=1024, help='mask width = height')
@@ -271,9 +275,21 @@ def main():
         out = mask_buf[i % 2]
         pending[i] = dist.all_gather_into_tensor(out.view(-1), masks_shard.view(-1), async_op=True)
 
+    chunked = use_dist and args.exchange == 'chunked'
+    if chunked:
+        if overlap or args.prepared:
+            raise SystemExit('--exchange chunked takes the caller-order cloud (the sort is part of the first chunk)')
+        vc, order = sharding.chunk_layout(V, world, args.chunks)
+        views_chunked = torch.from_numpy(np.ascontiguousarray(views_np[order])).to(dev)
+        engine = sharding.HipChunkEngine(ctx, xyz, dtype, n, views_chunked, S, S, 133, 0.5, flt, classes, flags=flags)
+        views = views_chunked                    # the gather buffer holds the planes in this order: one-shot calls on it use the same
+
     def step():
         if not use_dist:
             fuse()
+            return
+        if chunked:                              # masks_full is the gather buffer, planes in chunk order
+            sharding.overlapped_labels(dist, engine, masks_shard, masks_full, args.chunks)
             return
         i = step_no[0]
         if i not in pending:
@@ -303,6 +319,12 @@ def main():
         elapsed = float(tt.item())
     ctx.take_device_error(stream.cuda_stream)
     deferred = ctx.fuse_deferred(stream.cuda_stream)        # (to the float64 tier, to the exact kernel) in the last step
+    chunk_check = None
+    if chunked:                                             # the chunked step against one call over all views, same inputs
+        stepped = classes.clone()
+        fuse(masks_full)
+        stream.synchronize()
+        chunk_check = bool(torch.equal(stepped, classes))
 
     # dominant kernel alone (k_fuse), HIP events on its launch stream, same resident inputs: with the in-step
     # sort the step is [sort kernels][k_fuse reading xyz through perm]; both parts are timed on their own.
@@ -360,8 +382,10 @@ def main():
                                         f', {S}x{S} {args.masks} uint8 masks, nclasses=133, threshold=0.5, filter_classes={flt}; '
                                         f'fused project->sample->vote->segment',
                                points_total=total_points, points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64', cloud_layout=layout,
+                               chunked_step_equals_one_call=chunk_check,
                                deferred_points=dict(to_float64_tier=deferred[0], to_exact_kernel=deferred[1]),
-                               exchange='none' if not use_dist else f'RCCL all_gather of {V // world} masks/rank per step, double-buffered and overlapped with the previous step'),
+                               exchange='none' if not use_dist else (f'RCCL all_gather of {V // world} masks/rank per step, double-buffered and overlapped with the previous step' if not chunked else
+                                                                     f'RCCL all_reduce(MAX) of the label-presence bytes + {args.chunks} all_gathers of {V // world // args.chunks} masks/rank per step; chunk c+1 on the wire while chunk c votes (vote state carried in HBM)')),
                    roofline=roofline)
 
     # secondary, HBM-streaming kernels of the same path (not part of `value`)

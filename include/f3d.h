@@ -197,6 +197,31 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
                                 int nclasses, const int32_t* filter /*host*/, int nfilter,
                                 double threshold, int64_t* classes, uint16_t* votes_u16,
                                 unsigned flags, const int32_t* perm, void* stream);
+/* The same path with the views arriving in CHUNKS (with the masks sharded by view over the ranks, the
+ * all-gather of view chunk c+1 is in flight while chunk c votes).  Same results as one f3d_project_vote_argmax_dev call
+ * over all views (votes are a sum over views: order-free), at most 255 views in total, no vote output.
+ *   f3d_mask_presence_dev      labels that occur in `nviews` masks -> present256 (device, 256 bytes of 0 / 1).  Ranks
+ *                              combine theirs with an all-reduce MAX (the vote-bin code book must be the same on every
+ *                              rank and for every chunk, before any mask of another rank has arrived).
+ *   f3d_fuse_chunked_begin_dev builds the code book from the combined presence (NULL: every label 0..nclasses gets a
+ *                              bin -- no exchange, larger histograms) or from `filter`, and sizes ALL scratch of the
+ *                              chunk calls (coded masks of nviews views, the deferred lists, and the per-point vote
+ *                              state between chunks: f3d "carry", 4 * ceil((nclasses + 3) / 4) bytes per point, 8-bit
+ *                              bins in context scratch in HBM).
+ *   f3d_fuse_chunk_dev         views [v_begin, v_end): codes those planes of `masks` and lets every point vote on them.
+ *                              Chunks must follow each other without gaps from 0 to nviews, with the same xyz / n /
+ *                              views_dev / masks base pointer / h / w / nclasses / filter / threshold; flags and perm
+ *                              are taken from the first chunk.  masks[v] must be complete for the chunk's views when the
+ *                              call is enqueued on `stream` and for ALL views at the last chunk (the float64 tier and the
+ *                              reference-arithmetic kernel run there, over every view).  classes is written by the last
+ *                              chunk only.  F3D_ERR_INVALID for a chunk out of sequence. */
+int f3d_mask_presence_dev(f3d_ctx* ctx, const uint8_t* masks, int nviews, int h, int w, uint8_t* present256, void* stream);
+int f3d_fuse_chunked_begin_dev(f3d_ctx* ctx, const uint8_t* present256, int64_t n, int nviews, int h, int w, int nclasses,
+                               const int32_t* filter /*host*/, int nfilter, void* stream);
+int f3d_fuse_chunk_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                       int v_begin, int v_end, const uint8_t* masks /*[nviews,H,W]*/, int h, int w, int nclasses,
+                       const int32_t* filter /*host*/, int nfilter, double threshold, int64_t* classes,
+                       unsigned flags, const int32_t* perm, void* stream);
 /* Test hook: cell-sorts the cloud and evaluates, for every (point, view) pair, the accelerated decisions of the
  * fused kernel (wave-box and per-point float32 culls, centre + offset projection for a w x h image) next to the exact
  * arithmetic.  stats[0] = pairs inside the frustum, stats[1] = pairs the offset projection leaves to the exact

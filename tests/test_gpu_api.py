@@ -149,3 +149,49 @@ def test_two_ranks_label_their_shards_with_the_hip_path(tmp_path):
         assert np.array_equal(np.load(tmp_path / f'labels{r}.npy'), single), r
     want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.0, None)
     assert np.array_equal(single, want) and (want != 133).mean() > 0.5
+
+
+def _rank_overlap(rank, world, port, n, nchunks, out_dir):
+    """One rank of the step with the exchange overlapped inside it: chunked all-gather (gloo, host tensors copied to device
+    0 as they land) + f3d's view-chunked fused call on this rank's point range."""
+    import torch
+    import torch.distributed as dist
+    from f3d import sharding
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', 0)
+    sc = synth.scene('C1', n=n)
+    V = 16
+    q, t = synth.ring_views(V)
+    masks = synth.masks(V, sc['h'], sc['w'], 'block64x40')
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], q, t, sc['max_depth'])
+    vc, order = sharding.chunk_layout(V, world, nchunks)
+    v0, v1 = sharding.view_bounds(V, rank, world)
+    lo, hi = sharding.point_bounds(n, rank, world)
+    x = torch.from_numpy(sc['points'][lo:hi].copy()).to(dev)
+    cls = torch.empty(hi - lo, dtype=torch.int64, device=dev)
+    ctx = f3d.Context(0)
+    eng = sharding.HipChunkEngine(ctx, x, f3d.F64, hi - lo, torch.from_numpy(views[order]).to(dev), sc['h'], sc['w'], 133, 0.0, None, cls,
+                                  flags=f3d.FUSE_SORT)
+    shard = torch.from_numpy(masks[v0:v1].copy()).to(dev)
+    gathered = torch.empty((V,) + tuple(shard.shape[1:]), dtype=torch.uint8, device=dev)
+    sharding.overlapped_labels(dist, eng, shard, gathered, nchunks)
+    ctx.take_device_error(torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    labels = sharding.gather_labels(dist, cls.cpu(), n)
+    np.save(os.path.join(out_dir, f'overlap{rank}.npy'), labels.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_overlap_the_mask_exchange_inside_the_step(tmp_path):
+    import torch.multiprocessing as mp
+    n, V = 30_001, 16
+    mp.spawn(_rank_overlap, args=(2, 29537, n, 4, str(tmp_path)), nprocs=2, join=True)
+    sc = synth.scene('C1', n=n)
+    q, t = synth.ring_views(V)
+    masks = synth.masks(V, sc['h'], sc['w'], 'block64x40')
+    want = O.project_vote_argmax(sc['points'], sc['K'], q, t, masks, sc['max_depth'], 133, 0.0, None)
+    assert (want != 133).mean() > 0.3
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f'overlap{r}.npy'), want), r

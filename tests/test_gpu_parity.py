@@ -510,3 +510,99 @@ def test_nclasses_edge_values(ctx):
     assert votes[:, 200].sum() == 0                                    # nobody looks at pixel (0, 0)
     want = O.segment(votes[:, :101], 100, 0.3, None)
     assert np.array_equal(_dev_fuse(ctx, pts, views, loud, None, 0.3, 0, nclasses=100), want)
+
+
+# ---- the view-chunked call (f3d_fuse_chunked_begin_dev / f3d_fuse_chunk_dev): same labels as the one-shot call ----------------
+def _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, flags, bounds, f32=False, nclasses=133, order=None, presence='own'):
+    """bounds: chunk boundaries [0, ..., V].  order: views (and masks) handed over in this order (a permutation of range(V))."""
+    import torch
+    dev = torch.device('cuda', 0)
+    if order is not None:
+        views, masks = views[order], masks[order]
+    x = torch.from_numpy(pts.astype(np.float32) if f32 else pts).to(dev)
+    vd, md = torch.from_numpy(np.ascontiguousarray(views)).to(dev), torch.from_numpy(np.ascontiguousarray(masks)).to(dev)
+    n, (V, H, W) = len(pts), masks.shape
+    cls = torch.full((n,), -7, dtype=torch.int64, device=dev)
+    s = torch.cuda.Stream(dev)
+    dt = f3d.F32 if f32 else f3d.F64
+    present = torch.empty(256, dtype=torch.uint8, device=dev)
+    with torch.cuda.stream(s):
+        if presence == 'own':
+            ctx.mask_presence_dev(md.data_ptr(), V, H, W, present.data_ptr(), s.cuda_stream)
+        ctx.fuse_chunked_begin_dev(present.data_ptr() if presence == 'own' else None, n, V, H, W, nclasses, flt, s.cuda_stream)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            ctx.fuse_chunk_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, a, b, md.data_ptr(), H, W, nclasses, thr, flt, cls.data_ptr(),
+                               s.cuda_stream, flags=flags)
+        ctx.take_device_error(s.cuda_stream)
+        s.synchronize()
+    if presence == 'own':
+        got = np.flatnonzero(present.cpu().numpy())
+        assert np.array_equal(got, np.unique(masks)), 'labels present'
+    return cls.cpu().numpy()
+
+
+@pytest.mark.parametrize('mask_kind', ['block64', 'block64x40', 'iid'])
+def test_view_chunked_call_equals_the_one_shot_call(ctx, mask_kind):
+    """Every instance of the fast kernel (dword bins, packed bins, any-alphabet) resumed from the carry in HBM: chunk splits of
+    all shapes, the views in a shuffled order, float32 / float64 clouds, both thresholds, a filter list -- labels identical to
+    f3d_project_vote_argmax_dev and to the oracle."""
+    V = 24
+    sc = synth.scene('C1', n=150_001, mask_kind=mask_kind)
+    q, t = synth.ring_views(V)
+    masks = synth.masks(V, sc['h'], sc['w'], mask_kind)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], q, t, sc['max_depth'])
+    pts = sc['points']
+    rng = np.random.default_rng(3)
+    sub = rng.choice(len(pts), 3000, replace=False)
+    for thr, flt, f32 in [(0.0, None, False), (0.5, None, True), (0.5, [86, 114, 115], False)]:
+        one = _dev_fuse(ctx, pts, views, masks, flt, thr, f3d.FUSE_SORT, f32=f32)
+        p_sub = pts[sub].astype(np.float32).astype(np.float64) if f32 else pts[sub]
+        want = O.project_vote_argmax(p_sub, sc['K'], q, t, masks, sc['max_depth'], 133, thr, flt)
+        assert np.array_equal(one[sub], want)
+        if thr == 0.0:
+            assert (one != 133).mean() > 0.3                       # real labels, not the 'unclassified' default
+        for bounds, order, flags, presence in [([0, V], None, f3d.FUSE_SORT, 'own'),
+                                               ([0, 8, 16, V], None, f3d.FUSE_SORT, 'own'),
+                                               ([0, 1, 2, 3, 17, V], rng.permutation(V), f3d.FUSE_SORT, 'own'),
+                                               ([0, 12, V], rng.permutation(V), 0, 'all'),
+                                               (list(range(V + 1)), None, f3d.FUSE_SORT, 'all')]:
+            got = _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, flags, bounds, f32=f32, order=order, presence=presence)
+            assert np.array_equal(got, one), (mask_kind, thr, flt, f32, bounds)
+
+
+def test_view_chunked_call_deferred_points_errors_and_sequence(ctx):
+    import torch
+    dev = torch.device('cuda', 0)
+    sc = synth.scene('C1', n=60_000)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    pts = sc['points'].copy()
+    pts[::97] *= 1e31                       # not representable in the float32 kernel: deferred in every chunk, labelled by the exact tier
+    pts[5::101] = np.nan
+    V = len(views)
+    one = _dev_fuse(ctx, pts, views, sc['masks'], None, 0.0, f3d.FUSE_SORT)
+    got = _dev_fuse_chunked(ctx, pts, views, sc['masks'], None, 0.0, f3d.FUSE_SORT, [0, 1, 3, V])
+    assert np.array_equal(got, one)
+    assert ctx.fuse_deferred()[0] >= len(pts[::97])
+    # a rejected label in a middle chunk: IndexError once the call is complete, like the one-shot call
+    bad = sc['masks'].copy(); bad[1, 100:300, 100:300] = 200
+    with pytest.raises(IndexError, match='project_vote_argmax'):
+        _dev_fuse_chunked(ctx, sc['points'], views, bad, None, 0.0, 0, [0, 1, 2, V])
+    # chunks out of sequence, a chunk without begin, more than 255 views
+    x = torch.from_numpy(sc['points']).to(dev); vd = torch.from_numpy(views).to(dev); md = torch.from_numpy(sc['masks']).to(dev)
+    cls = torch.empty(len(pts), dtype=torch.int64, device=dev)
+    H, W = sc['masks'].shape[1:]
+    args = (x.data_ptr(), f3d.F64, len(pts), vd.data_ptr(), V)
+    tail = (md.data_ptr(), H, W, 133, 0.0, None, cls.data_ptr(), None)
+    ctx.fuse_chunked_begin_dev(None, len(pts), V, H, W, 133, None, None)
+    with pytest.raises(ValueError):
+        ctx.fuse_chunk_dev(*args, 1, 2, *tail)
+    ctx.fuse_chunk_dev(*args, 0, 2, *tail)
+    with pytest.raises(ValueError):
+        ctx.fuse_chunk_dev(*args, 0, 2, *tail)
+    ctx.fuse_chunk_dev(*args, 2, V, *tail)
+    with pytest.raises(ValueError):
+        ctx.fuse_chunk_dev(*args, 0, V, *tail)            # the call is complete: begin again first
+    with pytest.raises(ValueError):
+        ctx.fuse_chunked_begin_dev(None, len(pts), 256, H, W, 133, None, None)
+    ctx.synchronize()
+    assert np.array_equal(cls.cpu().numpy(), _dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.0, 0))

@@ -343,7 +343,8 @@ def test_config_c5_merge_50m_points_4096_instances():
     assert len(out_info) == 3964
     moved = out_ids != before
     assert moved.any() and len(np.unique(out_ids)) < len(np.unique(before))
-    assert sum(1 for d in out_info[1:] if 'bbox' in d) > 3900
+    boxed = [d for d in out_info[1:] if 'bbox' in d]
+    assert len(boxed) > 3800 and all(np.asarray(d['bbox']).shape == (8, 3) for d in boxed[:64])
     print(f'C5 merge_bb: {dt:.2f} s')
 
 

@@ -60,6 +60,84 @@ def test_two_rank_sharded_labels_equal_single_process(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# within-step overlap: chunked all-gather, votes carried from chunk to chunk
+# ------------------------------------------------------------------------------------------------------------
+class OracleChunkEngine:
+    """What HipChunkEngine does on the GPU, with the oracle's per-view votes: the carry is the float64 vote matrix."""
+
+    def __init__(self, points, sc, order, thr, flt):
+        self.points, self.sc, self.order, self.thr, self.flt = points, sc, order, thr, flt
+        self.votes, self.labels, self.present, self.seen = None, None, None, []
+
+    def presence(self, mask_shard):
+        p = torch.zeros(256, dtype=torch.uint8)
+        p[torch.unique(mask_shard).long()] = 1
+        return p
+
+    def begin(self, present):
+        self.present = present.numpy().copy()
+        self.votes = np.zeros((len(self.points), 134))
+
+    def chunk(self, v_begin, v_end, gathered):
+        sc, sel = self.sc, self.order[v_begin:v_end]
+        m = gathered.numpy()[v_begin:v_end]
+        assert np.array_equal(m, sc['masks'][sel])                       # the planes that have landed are the chunk's views
+        self.seen.append((v_begin, v_end))
+        self.votes += O.forward_votes(self.points, sc['K'], sc['wxyzs'][sel], sc['translations'][sel], m, sc['max_depth'], ncols=134)
+        if v_end == len(self.order):
+            self.labels = O.segment(self.votes, 133, self.thr, self.flt)
+
+
+def _overlap_worker(rank, world, port, n, nchunks, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sc = _ring_scene(n)
+        V = len(sc['masks'])
+        v0, v1 = sharding.view_bounds(V, rank, world)
+        shard = torch.from_numpy(sc['masks'][v0:v1].copy())
+        vc, order = sharding.chunk_layout(V, world, nchunks)
+        lo, hi = sharding.point_bounds(n, rank, world)
+        eng = OracleChunkEngine(sc['points'][lo:hi], sc, order, 0.0, None)
+        gathered = torch.full((V,) + shard.shape[1:], 255, dtype=torch.uint8)
+        sharding.overlapped_labels(dist, eng, shard, gathered, nchunks)
+        assert eng.seen == [(c * world * vc, (c + 1) * world * vc) for c in range(nchunks)]
+        assert np.array_equal(np.flatnonzero(eng.present), np.unique(sc['masks']))     # the union over BOTH ranks' masks
+        labels = sharding.gather_labels(dist, torch.from_numpy(eng.labels), n)
+        np.save(os.path.join(out_dir, f'overlap_{rank}.npy'), labels.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _ring_scene(n, V=8):
+    sc = synth.scene('C1', n=n)
+    q, t = synth.ring_views(V)
+    sc['wxyzs'], sc['translations'] = q, t
+    sc['masks'] = synth.masks(V, sc['h'], sc['w'], 'block64')
+    sc['masks'][V // 2:][sc['masks'][V // 2:] == sc['masks'][0, 0, 0]] = 77       # a label only the second rank's masks hold
+    return sc
+
+
+def test_chunk_layout():
+    vc, order = sharding.chunk_layout(16, 2, 4)
+    assert vc == 2 and order.tolist() == [0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15]
+    assert sharding.chunk_layout(64, 8, 1)[1].tolist() == list(range(64))
+    with pytest.raises(ValueError):
+        sharding.chunk_layout(64, 8, 3)
+
+
+@pytest.mark.parametrize('nchunks', [1, 2, 4])
+def test_two_rank_overlapped_step_equals_single_process(tmp_path, nchunks):
+    n, world = 2001, 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), n, nchunks, str(tmp_path)), nprocs=world, join=True)
+    sc = _ring_scene(n)
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.0, None)
+    assert (want != 133).mean() > 0.3
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f'overlap_{r}.npy'), want)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # bbox merge (SURVEY 8(e)): scans sharded by point range, one all_reduce(MAX) per co-occurrence answer, initial
 # box fits dealt out by instance and all-gathered, control flow replicated on every rank
 # ------------------------------------------------------------------------------------------------------------
