@@ -118,6 +118,7 @@ __device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W) {        
 #define F3D_CODE_BAD 1u
 #define F3D_CODE_OTHER 2u
 #define F3D_PACKED_SMALL_WORDS 12             // packed 8-bit bins: alphabets up to 48 codes get the medium-LDS instance
+#define F3D_BOOK_DWORDS 256                  // lut + inv + cmin of f3d_codebook, staged in LDS by k_fuse
 #define F3D_BIN32_MAX_CODES 12               // alphabets up to this many codes vote into dword bins (12 KiB of LDS per 256 points: 4 blocks per CU)
 
 // One view of the coded masks: (ceil(H/8) + 2) x (ceil(W/8) + 2) tiles of 8x8 pixels (64 B each): the image plus a one-tile border of
@@ -182,6 +183,18 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_presence_bytes(f3d_codebook* __re
     if (to_bytes) { bytes256[l] = (uint8_t)((cb->presence[l >> 5] >> (l & 31u)) & 1u); return; }
     const unsigned long long m = __ballot(bytes256[l] != 0);
     if ((l & 63u) == 0u) { cb->presence[l >> 5] = (unsigned)m; cb->presence[(l >> 5) + 1] = (unsigned)(m >> 32); }
+}
+
+// cb->cmin for this call's threshold (see segment_point): thread t finds, by bisection with the reference's own float64 division,
+// how many c in 0..t give c / t < threshold.  One block of 256 threads.
+__global__ __launch_bounds__(F3D_BLOCK) void k_threshold_table(f3d_codebook* __restrict__ cb, double threshold) {
+    const int t = threadIdx.x;
+    int lo = 0, hi = t + 1;                                   // c in [lo, hi): the first c that is NOT below the threshold
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((double)mid / (double)t < threshold) lo = mid + 1; else hi = mid;
+    }
+    cb->cmin[t] = (uint16_t)lo;                               // t = 0 is never looked up (no votes: voting.py:126)
 }
 
 // one block of 256 threads: thread l decides the code of label l.  book: 0 = every label 0..nclasses has a bin (no
@@ -376,7 +389,8 @@ __device__ __forceinline__ void project_offset2(const centre_row& r, f32x2 DX, f
 // offset of pixel (U8 + fi0, V8 + fi1) in the view's coded plane = obase + this; c_row = 64 * pitch - 64.
 // (fi + 56 (fi >> 3) = (fi & 7) + 64 (fi >> 3), and 8 fi + (64 pitch - 64)(fi >> 3) = 8 (fi & 7) + 64 pitch (fi >> 3); arithmetic shifts.)
 __device__ __forceinline__ unsigned rel_offset(int fi0, int fi1, int c_row) {
-    return (unsigned)((fi0 + 56 * (fi0 >> 3)) + ((fi1 << 3) + c_row * (fi1 >> 3)));
+    // 24-bit multiplies (v_mad_i32_i24, full rate; a 32-bit v_mul_lo_u32 costs four issue slots): |fi| >> 3 and c_row are far below 2^23
+    return (unsigned)((fi0 + __mul24(fi0 >> 3, 56)) + ((fi1 << 3) + __mul24(fi1 >> 3, c_row)));
 }
 
 // single point (audit kernel): absolute pixel and "proven"
@@ -417,13 +431,18 @@ __device__ __forceinline__ void vote_add(vote_state<MODE>& st, uint32_t* hist, i
 }
 
 // VotingSegmentation.segment (voting.py:120-135) for one point given the winner, then the store
+// cmin (optional, totals up to 255 only): cmin[t] = the number of c in 0..t with (double)c / (double)t < threshold -- the float64
+// division of voting.py:128 is monotone in c, so "max / total < threshold" is "max < cmin[total]" (k_threshold_table builds it with
+// that very division; a table look-up instead of a ~40-instruction IEEE division per point)
 template <typename FilterAt>
-__device__ __forceinline__ int64_t segment_point(int win_c, int win_i, int total, int nfilter, FilterAt fat, int nclasses, double threshold) {
+__device__ __forceinline__ int64_t segment_point(int win_c, int win_i, int total, int nfilter, FilterAt fat, int nclasses, double threshold,
+                                                 const uint16_t* cmin = nullptr) {
     int64_t cls;
     if (total == 0) cls = nclasses;                                                // :126
     else {
         cls = win_i;
-        if ((double)win_c / (double)total < threshold) cls = nclasses;             // :128-130
+        const bool low = cmin ? win_c < (int)cmin[total] : (double)win_c / (double)total < threshold;
+        if (low) cls = nclasses;                                                   // :128-130
         if (win_c == 0) cls = nclasses;                                            // :131
     }
     if (nfilter > 0) {                                                             // sequential remap (Q3)
@@ -472,7 +491,8 @@ __device__ __forceinline__ void vote_bin32(uint32_t* hcol, unsigned b) { atomicA
 template <bool WRITE_VOTES>
 __device__ __forceinline__ void finish_bin32(const uint32_t* hcol, int ncodes, const uint8_t* lut, const uint8_t* inv, int nfilter,
                                              const int* __restrict__ fcls, int nclasses, double threshold, bool store, int orig,
-                                             int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad) {
+                                             int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad,
+                                             const uint16_t* cmin = nullptr) {
     const int ncols = nclasses + 1;
     const unsigned cbad = hcol[F3D_BLOCK];
     bad = cbad != 0u;
@@ -495,7 +515,7 @@ __device__ __forceinline__ void finish_bin32(const uint32_t* hcol, int ncodes, c
     } else {
         win_c = (int)(best >> 8); win_i = (int)inv[best & 0xFFu];
     }
-    const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold);
+    const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold, cmin);
     if (store) classes[orig] = cls;
     if (WRITE_VOTES && store) {
         for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? hcol[b * F3D_BLOCK] : 0u); }
@@ -522,7 +542,8 @@ __device__ __forceinline__ unsigned coded_count(const uint32_t* hcol, unsigned b
 template <bool WRITE_VOTES, bool WRAP>
 __device__ __forceinline__ bool finish_coded(unsigned nvalid, const uint32_t* hcol, int words, const uint8_t* lut, const uint8_t* inv,
                                              int nfilter, const int* __restrict__ fcls, int nclasses, double threshold, bool store,
-                                             int orig, int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad) {
+                                             int orig, int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad,
+                                             const uint16_t* cmin = nullptr) {
     const int ncols = nclasses + 1;
     unsigned best = 0, sum = 0;
     {
@@ -560,7 +581,7 @@ __device__ __forceinline__ bool finish_coded(unsigned nvalid, const uint32_t* hc
         win_c = (int)(best >> 8); win_i = (int)inv[best & 0xFFu];
     }
     // total = the votes cast (every bin but "no sample"; a rejected label raises IndexError anyway)
-    const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold);
+    const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold, cmin);
     if (store) classes[orig] = cls;
     if (WRITE_VOTES && store) {                                                    // presence book: an absent label reads bin 0 = 0
         for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? coded_count(hcol, b) : 0u); }
@@ -588,6 +609,29 @@ __device__ __forceinline__ float wave_reduce(float v) {
     if (MAX) F3D_DPP_CHAIN("v_max_f32_dpp"); else F3D_DPP_CHAIN("v_min_f32_dpp");
 #undef F3D_DPP_CHAIN
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// The bounding box of a wave: three minima and three maxima reduced together.  The six chains are interleaved step by step, so the
+// two wait states a DPP read needs after a VALU write of the same register are filled with the other chains' instructions instead
+// of s_nop (36 VALU for the box instead of 36 + 42 idle issue slots).
+__device__ __forceinline__ void wave_box(float& lo0, float& hi0, float& lo1, float& hi1, float& lo2, float& hi2) {
+#define F3D_STEP(ctrl)                                                \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_max_f32_dpp %1, %1, %1 " ctrl "\n\t" \
+    "v_min_f32_dpp %2, %2, %2 " ctrl "\n\tv_max_f32_dpp %3, %3, %3 " ctrl "\n\t" \
+    "v_min_f32_dpp %4, %4, %4 " ctrl "\n\tv_max_f32_dpp %5, %5, %5 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 F3D_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 F3D_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 F3D_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 F3D_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 F3D_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 F3D_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1"
+                 : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1), "+v"(lo2), "+v"(hi2));
+#undef F3D_STEP
+#define F3D_L63(x) x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63))
+    F3D_L63(lo0); F3D_L63(hi0); F3D_L63(lo1); F3D_L63(hi1); F3D_L63(lo2); F3D_L63(hi2);
+#undef F3D_L63
 }
 
 // ------------------------------------------------------------------------------------------
@@ -652,9 +696,10 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     // TLDS: the per-view constants of a 64-view group are staged in LDS; otherwise (the any-alphabet instance, whose histograms need the
     // room) they are read from the transposed global tables ctabT / vtabT
     float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes (+ image size) of one view group
-    uint32_t* lutw = TLDS ? lds_u32 + 64 * F3D_CULL_ROW : lds_u32;        // lut[256] then inv[256] (bytes)
-    double* vtab = reinterpret_cast<double*>(lutw + 128);                 // [F3D_VHEAD][64]: M, t, mnorm of the group's views
-    uint32_t* hist = TLDS ? lutw + 128 + 2 * F3D_VHEAD * 64 : lutw + 128; // [PPL][hdw][F3D_BLOCK]
+    uint32_t* lutw = TLDS ? lds_u32 + 64 * F3D_CULL_ROW : lds_u32;        // lut[256], inv[256] (bytes), cmin[256] (uint16): F3D_BOOK_DWORDS
+    double* vtab = reinterpret_cast<double*>(lutw + F3D_BOOK_DWORDS);     // [F3D_VHEAD][64]: M, t, mnorm of the group's views
+    uint32_t* hist = TLDS ? lutw + F3D_BOOK_DWORDS + 2 * F3D_VHEAD * 64 : lutw + F3D_BOOK_DWORDS; // [PPL][hdw][F3D_BLOCK]
+    const uint16_t* vmin = (WRAP || nviews > 255) ? nullptr : reinterpret_cast<const uint16_t*>(lutw + 128);   // totals beyond 255: the division itself
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
     const uint8_t* inv = lut + 256;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
@@ -668,7 +713,17 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     const int ngroups = (nviews + 63) >> 6;
     const float umaxf = (float)(W > H ? W : H), Wf = (float)W, Hf = (float)H;
 
-    if (tid < 128) lutw[tid] = reinterpret_cast<const uint32_t*>(cb->lut)[tid];   // lut and inv are adjacent in the book
+    // the coded masks as a raw buffer resource: a gather is then buffer_load_ubyte with the 32-bit offset as it is (a flat global load
+    // wants a 64-bit address: two more vector instructions per gather)
+    const __amdgpu_buffer_rsrc_t cm_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(cmasks), 0, (int)((unsigned)nviews * plane), 0x00020000);
+#if defined(F3D_EXP_GATHER) && F3D_EXP_GATHER == 1     // timing experiments only (results are wrong): every lane reads the same 64 bytes
+    auto gather = [&](unsigned off) -> unsigned { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(cm_rsrc, (int)(off & 63u), 0, 0); };
+#elif defined(F3D_EXP_GATHER) && F3D_EXP_GATHER == 2   // no memory instruction at all
+    auto gather = [&](unsigned off) -> unsigned { return off & 2u; };
+#else
+    auto gather = [&](unsigned off) -> unsigned { return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(cm_rsrc, (int)off, 0, 0); };
+#endif
+    lutw[tid] = reinterpret_cast<const uint32_t*>(cb->lut)[tid];          // lut, inv and cmin are adjacent in the book (256 dwords)
     auto stage_group = [&](int g) {                                       // whole block; caller brackets with barriers
         const int nv = min(64, nviews - 64 * g);
         for (int k = tid; k < nv * 24; k += F3D_BLOCK) {
@@ -721,9 +776,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 }
             }
             // ---- (A) bounding box of this wave's live, well-behaved points
-            lo0 = wave_reduce<false>(lo0); hi0 = wave_reduce<true>(hi0);
-            lo1 = wave_reduce<false>(lo1); hi1 = wave_reduce<true>(hi1);
-            lo2 = wave_reduce<false>(lo2); hi2 = wave_reduce<true>(hi2);
+            wave_box(lo0, hi0, lo1, hi1, lo2, hi2);
             wave_any = __any(act[0] | act[1]);
             c0 = 0.5f * (lo0 + hi0); c1 = 0.5f * (lo1 + hi1); c2 = 0.5f * (lo2 + hi2);
             e0 = 0.5f * (hi0 - lo0) * 1.000002f + 1e-30f; e1 = 0.5f * (hi1 - lo1) * 1.000002f + 1e-30f;
@@ -733,7 +786,12 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             DX = (f32x2){(float)(p[0].x - (double)c0), (float)(p[1].x - (double)c0)};
             DY = (f32x2){(float)(p[0].y - (double)c1), (float)(p[1].y - (double)c1)};
             DZ = (f32x2){(float)(p[0].z - (double)c2), (float)(p[1].z - (double)c2)};
+            // a lane without a usable point carries NaN offsets: every comparison of the view loop is then false for it (no cull
+            // passed, no pixel proven, nothing gathered), so the loop needs no "active" flag
+            if (!act[0]) { DX.x = __builtin_nanf(""); }
+            if (!act[1]) { DX.y = __builtin_nanf(""); }
         }
+        unsigned unsure[2] = {0u, 0u};                       // a visible view left one of the point's decisions unproven
         if (CARRY && (chunk_flags & 1)) {                                   // the bins (and the deferred flag) of the earlier view chunks
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
@@ -806,6 +864,9 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             // Taken F3D_CHUNK at a time: project the chunk, retire the previous chunk's votes, then issue the chunk's mask
             // gathers back to back -- 2 * F3D_CHUNK gathers in flight per wave, each with a whole chunk of arithmetic to land.
             unsigned long long todo_v = valid_m & ~out_m & in_m & row_m;
+#if defined(F3D_EXP_SKIP) && (F3D_EXP_SKIP == 1 || F3D_EXP_SKIP == 3)   // timing experiment: no whole-wave views
+            todo_v = 0ull;
+#endif
             while (todo_v) {
                 int cbit[F3D_CHUNK]; unsigned coff[2][F3D_CHUNK];
                 bool use[F3D_CHUNK];
@@ -822,15 +883,15 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) {
-                        const bool hit = safe[q] & act[q] & use[k];
-                        defer[q] = defer[q] | (!safe[q] & act[q] & use[k]);
-                        coff[q][k] = hit ? r.obase + rel_offset(fi0[q], fi1[q], c_row) : 0u;   // offset 0: a border tile, "no sample"
+                        unsure[q] = safe[q] ? unsure[q] : 1u;                  // (an unused slot repeats a row of this chunk: same answer)
+                        const unsigned o = r.obase + rel_offset(fi0[q], fi1[q], c_row);   // computed for every lane: a select, not a branch
+                        coff[q][k] = (safe[q] & use[k]) ? o : 0u;              // offset 0: a border tile, "no sample"
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) { vote(0, ccode[0][k]); vote(1, ccode[1][k]); }
 #pragma unroll
-                for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = cmasks[coff[0][k]]; if (PPL == 2) ccode[1][k] = cmasks[coff[1][k]]; }
+                for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = gather(coff[0][k]); if (PPL == 2) ccode[1][k] = gather(coff[1][k]); }
             }
 #pragma unroll
             for (int k = 0; k < F3D_CHUNK; ++k) {
@@ -840,6 +901,11 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             // every other visible view: per-point cull in offset form, image-range test; a lane inside the rounding margin of a
             // plane, or a view without a usable centre row, sends the point to the next tier
             todo_v = valid_m & ~out_m & ~(in_m & row_m);
+#if defined(F3D_EXP_SKIP) && F3D_EXP_SKIP == 2         // timing experiment: no mixed views
+            todo_v = 0ull;
+#elif defined(F3D_EXP_SKIP) && F3D_EXP_SKIP == 3       // neither: the per-tile prologue and epilogue alone
+            todo_v = 0ull;
+#endif
             while (todo_v) {
                 const int bit = __builtin_ctzll(todo_v);
                 todo_v &= todo_v - 1ull;
@@ -870,22 +936,24 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) {
-                        const bool inside = act[q] & sure[q];
+                        const bool inside = sure[q];
                         const bool hit = inside & safe[q] & ((unsigned)(fi0[q] + U8) < (unsigned)W) & ((unsigned)(fi1[q] + V8) < (unsigned)H);
-                        defer[q] = defer[q] | (act[q] & maybe[q] & !sure[q]) | (inside & !safe[q]);
-                        off[q] = hit ? r.obase + rel_offset(fi0[q], fi1[q], c_row) : 0u;
+                        unsure[q] = ((maybe[q] & !sure[q]) | (inside & !safe[q])) ? 1u : unsure[q];
+                        const unsigned o = r.obase + rel_offset(fi0[q], fi1[q], c_row);
+                        off[q] = hit ? o : 0u;
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) defer[q] = defer[q] | (act[q] & maybe[q]);   // the box comes too close to this view's camera plane
+                    for (int q = 0; q < PPL; ++q) unsure[q] = maybe[q] ? 1u : unsure[q];      // the box comes too close to this view's camera plane
                 }
                 vote(0, pend[0]); vote(1, pend[1]);
-                pend[0] = cmasks[off[0]]; if (PPL == 2) pend[1] = cmasks[off[1]];
+                pend[0] = gather(off[0]); if (PPL == 2) pend[1] = gather(off[1]);
             }
         }
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             vote(q, pend[q]);
+            defer[q] = defer[q] | (act[q] & (unsure[q] != 0u));
             uint32_t* hc = q ? hcol1 : hcol0;
             if (CARRY && (chunk_flags & 2)) {                                 // more views to come: park the bins in HBM
                 uint32_t* cq = carry + ((size_t)(tile * PPL + q) * words) * F3D_BLOCK + tid;
@@ -903,9 +971,9 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 continue;
             }
             bool bad = false, trusted = true;
-            if (BIN32) finish_bin32<WRITE_VOTES>(hc, ncodes, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q], classes, votes_out, bad);
+            if (BIN32) finish_bin32<WRITE_VOTES>(hc, ncodes, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q], classes, votes_out, bad, vmin);
             else trusted = finish_coded<WRITE_VOTES, WRAP>(nvalid[q], hc, words, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q],
-                                                           classes, votes_out, bad);
+                                                           classes, votes_out, bad, vmin);
             const bool d = defer[q] | (live[q] & !trusted);
             if (d) todo[atomicAdd(todo_count, 1u)] = gather_xyz ? orig[q] : (i0 + 64 * q);     // index into xyz as this launch sees it
             if (bad & !d) atomicOr(err, F3D_DEVERR_FUSE);
@@ -1165,7 +1233,7 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 #endif
 
 static size_t fuse_lds_bytes(int hist_dwords_per_point, int ppl, bool tables = true) {   // k_fuse: [tables +] code book + histograms of `ppl` points per lane
-    return ((tables ? 64 * F3D_CULL_ROW + 2 * F3D_VHEAD * 64 : 0) + 128) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
+    return ((tables ? 64 * F3D_CULL_ROW + 2 * F3D_VHEAD * 64 : 0) + F3D_BOOK_DWORDS) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
 }
 size_t f3d_fuse_carry_bytes(int64_t n, int nclasses) {     // packed bins of every point slot of the 256- or 512-point tiles
     const size_t words_max = (size_t)((nclasses + 1 + 2 + 3) >> 2);
@@ -1277,6 +1345,7 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
     hipError_t e;
     if (fast) {
         const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
+        hipLaunchKernelGGL(k_threshold_table, dim3(1), dim3(F3D_BLOCK), 0, s, const_cast<f3d_codebook*>(cb), threshold);
         auto ks = k_fuse<T, 2, V, true, false, true, CARRY>;     // dword bins: at most F3D_BIN32_MAX_CODES codes
         // 8-bit bins, 4 per dword, 2 points per lane;  any alphabet: 1 point per lane, tables in global memory
         auto km2 = k_fuse<T, 2, V, false, false, true, CARRY>;

@@ -46,6 +46,7 @@ struct f3d_filter_args {                   // filter_classes of VotingSegmentati
 struct f3d_codebook {
     uint8_t lut[256];                      // label -> bin code (0 = no sample / absent label, 1 = rejected label, ...)
     uint8_t inv[256];                      // bin code -> label (must follow lut directly: the kernels stage both with one copy)
+    uint16_t cmin[256];                    // (must follow inv directly) cmin[t]: votes below which max / t < threshold (k_threshold_table)
     int ncodes, words, book, pad;          // bins in use, histogram dwords per thread = (ncodes + 3) / 4, 1 presence / 2 filter book
     unsigned presence[8];                  // bit l: label l occurs in the masks
 };

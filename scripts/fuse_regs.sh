@@ -13,6 +13,6 @@ for line in sys.stdin:
     if m and name:
         vals[m.group(1).split()[0]]=m.group(2)
         if m.group(1).startswith('Occupancy') and ('k_fuseI' in name or 'audit' in name):
-            short=re.sub(r'_ZN12_GLOBAL__N_1\d+','',name)[:24]
+            short=re.sub(r'_ZN12_GLOBAL__N_1\d+','',name)[:40]
             print(short, vals)
 "
