@@ -544,7 +544,12 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
     f3d_filter_args fa;
     if ((rc = make_filter(ctx, filter, nfilter, nclasses + 1, true, s, &fa))) return rc;
     bool gather = (flags & F3D_FUSE_GATHER) && perm;
-    if ((flags & F3D_FUSE_SORT) && n > 512 && n <= 0x7fffffffLL) {
+    const bool sort = (flags & F3D_FUSE_SORT) && n > 512 && n <= 0x7fffffffLL;
+    // the accelerated kernels address the coded masks with 32-bit offsets; beyond 4 GiB of them the exact kernel labels every point
+    const bool coded = nviews > 0 && nclasses <= F3D_CODE_MAX_NCLASSES && f3d_coded_masks_bytes(nviews, h, w) < ((size_t)1 << 32);
+    // (Measured and dropped: coding the masks on a second stream, forked from and joined into `stream` with events, while the cloud is
+    // sorted -- the two event dependencies cost more than the ~50 us of overlap they buy: 1.32 ms per C3 step instead of 1.26.)
+    if (sort) {
         void *sperm, *scratch;                                                                  // grow on first use only
         if ((rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &sperm))) return rc;
         if ((rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &scratch))) return rc;
@@ -552,17 +557,16 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
         perm = (const int32_t*)sperm; gather = true;                                            // the kernel reads xyz[perm[i]]
     }
     const uint8_t* cmasks = nullptr;                                                            // coded, tiled copy for the fast kernel
-    // the accelerated kernels address the coded masks with 32-bit offsets; beyond 4 GiB of them the exact kernel labels every point
-    if (nviews > 0 && nclasses <= F3D_CODE_MAX_NCLASSES && f3d_coded_masks_bytes(nviews, h, w) < ((size_t)1 << 32)) {
+    void *todo, *tables;                                                                        // grow on first use only
+    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
+    if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews > 0 ? nviews : 1), &tables))) return rc;
+    if (coded) {
         void* tm;                                                                               // grows on first use only
         if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &tm))) return rc;
         F3D_HIP(ctx, f3d_launch_code_masks(masks, (uint8_t*)tm, nviews, h, w, nclasses, fa, votes_u16 != nullptr, ctx->codebook, s));
+        F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, 0, nviews, tables, ctx->codebook, threshold, s));
         cmasks = (const uint8_t*)tm;
     }
-    void* todo;                                                                                 // grows on first use only
-    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
-    void* tables;                                                                               // grows on first use only
-    if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews > 0 ? nviews : 1), &tables))) return rc;
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,
                                  ctx->dev_err, perm, gather, (unsigned int*)todo, (int32_t*)((char*)todo + 16), ctx->codebook, tables,
                                  0, nviews, nullptr, nullptr, s));
@@ -647,6 +651,7 @@ int f3d_fuse_chunk_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n
     if ((rc = ensure(ctx, SLOT_FUSE_CARRY, f3d_fuse_carry_bytes(n, nclasses), &carry))) return rc;
     const size_t plane = f3d_coded_masks_bytes(1, h, w);
     F3D_HIP(ctx, f3d_launch_code_planes(masks + (size_t)v_begin * h * w, (uint8_t*)tm + (size_t)v_begin * plane, v_end - v_begin, h, w, ctx->codebook, s));
+    F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, v_begin, v_end, tables, ctx->codebook, threshold, s));
     F3D_HIP(ctx, f3d_launch_fuse(cxyz, dtype, n, views_dev, nviews, masks, (const uint8_t*)tm, h, w, nclasses, fa, threshold, classes, nullptr,
                                  ctx->dev_err, ctx->chunk.perm, cgather, (unsigned int*)todo, (int32_t*)((char*)todo + 16),
                                  ctx->codebook, tables, v_begin, v_end, (uint32_t*)carry, keep, s));

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_presence_bytes(f3d_codebook* __re
 
 // cb->cmin for this call's threshold (see segment_point): thread t finds, by bisection with the reference's own float64 division,
 // how many c in 0..t give c / t < threshold.  One block of 256 threads.
-__global__ __launch_bounds__(F3D_BLOCK) void k_threshold_table(f3d_codebook* __restrict__ cb, double threshold) {
+__device__ __forceinline__ void threshold_table(f3d_codebook* __restrict__ cb, double threshold) {
     const int t = threadIdx.x;
     int lo = 0, hi = t + 1;                                   // c in [lo, hi): the first c that is NOT below the threshold
     while (lo < hi) {
@@ -661,8 +661,10 @@ __device__ __forceinline__ void wave_box(float& lo0, float& hi0, float& lo1, flo
 #endif
 // [group][field][view] copies of the per-view constants the lanes-over-views prologue reads (24 floats: cull planes, margins, image
 // size; 15 doubles: M, t, mnorm), for the instance that cannot afford them in LDS: consecutive lanes read consecutive addresses
-__global__ __launch_bounds__(F3D_BLOCK) void k_views_tables(const f3d_view* __restrict__ views, int nviews, float* __restrict__ ctabT,
-                                                             double* __restrict__ vtabT) {
+__device__ __forceinline__ void threshold_table(f3d_codebook* __restrict__ cb, double threshold);
+__global__ __launch_bounds__(F3D_BLOCK) void k_fuse_setup(const f3d_view* __restrict__ views, int nviews, float* __restrict__ ctabT,
+                                                           double* __restrict__ vtabT, f3d_codebook* __restrict__ cb, double threshold) {
+    if (blockIdx.x == 0) threshold_table(cb, threshold);      // ... and the call's threshold table (segment_point)
     const int ngroups = (nviews + 63) >> 6;
     for (int k = blockIdx.x * F3D_BLOCK + threadIdx.x; k < ngroups * 64 * 39; k += gridDim.x * F3D_BLOCK) {
         const int v = k / 39, f = k - v * 39, g = v >> 6, l = v & 63;
@@ -1345,7 +1347,6 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
     hipError_t e;
     if (fast) {
         const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
-        hipLaunchKernelGGL(k_threshold_table, dim3(1), dim3(F3D_BLOCK), 0, s, const_cast<f3d_codebook*>(cb), threshold);
         auto ks = k_fuse<T, 2, V, true, false, true, CARRY>;     // dword bins: at most F3D_BIN32_MAX_CODES codes
         // 8-bit bins, 4 per dword, 2 points per lane;  any alphabet: 1 point per lane, tables in global memory
         auto km2 = k_fuse<T, 2, V, false, false, true, CARRY>;
@@ -1363,7 +1364,6 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
                                classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS,
                                ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
         if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS) {
-            hipLaunchKernelGGL(k_views_tables, dim3(8), b, 0, s, cviews, cnv, ctabT, vtabT);
             hipLaunchKernelGGL(kf, dim3(grid1), b, lds_full, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev,
                                threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 256,
                                ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
@@ -1387,6 +1387,17 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
         hipLaunchKernelGGL(ke, ge, b, lds_exact, s, (const T*)xyz, n, todo2_count, fast ? todo2 : nullptr, views_dev, nviews, masks, h, w, nclasses,
                            flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0);
     }
+    return hipGetLastError();
+}
+
+// Before f3d_launch_fuse, on any stream that is joined into its stream: the threshold table of the code book (segment_point) and the
+// transposed per-view tables of the views [v0, v1) the any-alphabet instance reads (tables: f3d_fuse_tables_bytes(nviews) of scratch).
+hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold, hipStream_t s) {
+    const int cnv = v1 - v0;
+    if (cnv <= 0) return hipSuccess;
+    float* ctabT = reinterpret_cast<float*>(tables);
+    double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((cnv + 63) / 64) * 64 * 24 * sizeof(float));
+    hipLaunchKernelGGL(k_fuse_setup, dim3(8), dim3(F3D_BLOCK), 0, s, views_dev + v0, cnv, ctabT, vtabT, cb, threshold);
     return hipGetLastError();
 }
 
