@@ -46,6 +46,9 @@ struct hist_traits;
 template <> struct hist_traits<MODE_HIST8> { static constexpr int per_word = 4, shift = 2, bits = 8; static constexpr uint32_t mask = 0xFFu; };
 template <> struct hist_traits<MODE_HIST16> { static constexpr int per_word = 2, shift = 1, bits = 16; static constexpr uint32_t mask = 0xFFFFu; };
 
+#ifndef F3D_GATHER_DEPTH
+#define F3D_GATHER_DEPTH 1                   // chunks of gathers in flight per wave (2: measured below)
+#endif
 #ifndef F3D_CHUNK
 #define F3D_CHUNK 2                          // whole-wave views projected per gather batch
 #endif
@@ -818,6 +821,14 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
         unsigned ccode[2][F3D_CHUNK];
 #pragma unroll
         for (int k = 0; k < F3D_CHUNK; ++k) ccode[0][k] = ccode[1][k] = F3D_CODE_NONE;
+#if F3D_GATHER_DEPTH == 2                                    // codes are voted two chunks after their gathers were issued
+        unsigned ccode2[2][F3D_CHUNK];
+#pragma unroll
+        for (int k = 0; k < F3D_CHUNK; ++k) ccode2[0][k] = ccode2[1][k] = F3D_CODE_NONE;
+#define F3D_OLDEST ccode2
+#else
+#define F3D_OLDEST ccode
+#endif
         auto vote = [&](int q, unsigned b) {
             if (q >= PPL) return;
             if (BIN32) vote_bin32(q ? hcol1 : hcol0, b);
@@ -890,13 +901,30 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                         coff[q][k] = (safe[q] & use[k]) ? o : 0u;              // offset 0: a border tile, "no sample"
                     }
                 }
+#ifndef F3D_NO_VOTE_PIN
+                // the previous chunk's codes are consumed only now, after this chunk's arithmetic: without this (empty) dependency the
+                // scheduler hoists the votes -- and with them the s_waitcnt for the gathers -- to the top of the iteration
 #pragma unroll
-                for (int k = 0; k < F3D_CHUNK; ++k) { vote(0, ccode[0][k]); vote(1, ccode[1][k]); }
+                for (int k = 0; k < F3D_CHUNK; ++k) {
+                    asm volatile("" : "+v"(F3D_OLDEST[0][k]) : "v"(coff[0][k]));
+                    if (PPL == 2) asm volatile("" : "+v"(F3D_OLDEST[1][k]) : "v"(coff[1][k]));
+                }
+#endif
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) { vote(0, F3D_OLDEST[0][k]); vote(1, F3D_OLDEST[1][k]); }
+#if F3D_GATHER_DEPTH == 2
+#pragma unroll
+                for (int k = 0; k < F3D_CHUNK; ++k) { ccode2[0][k] = ccode[0][k]; ccode2[1][k] = ccode[1][k]; }
+#endif
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = gather(coff[0][k]); if (PPL == 2) ccode[1][k] = gather(coff[1][k]); }
             }
 #pragma unroll
             for (int k = 0; k < F3D_CHUNK; ++k) {
+#if F3D_GATHER_DEPTH == 2
+                vote(0, ccode2[0][k]); vote(1, ccode2[1][k]);
+                ccode2[0][k] = ccode2[1][k] = F3D_CODE_NONE;
+#endif
                 vote(0, ccode[0][k]); vote(1, ccode[1][k]);
                 ccode[0][k] = ccode[1][k] = F3D_CODE_NONE;
             }
@@ -948,6 +976,10 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) unsure[q] = maybe[q] ? 1u : unsure[q];      // the box comes too close to this view's camera plane
                 }
+#ifndef F3D_NO_VOTE_PIN
+                asm volatile("" : "+v"(pend[0]) : "v"(off[0]));
+                if (PPL == 2) asm volatile("" : "+v"(pend[1]) : "v"(off[1]));
+#endif
                 vote(0, pend[0]); vote(1, pend[1]);
                 pend[0] = gather(off[0]); if (PPL == 2) pend[1] = gather(off[1]);
             }
