@@ -121,6 +121,9 @@ __device__ __forceinline__ unsigned mask_offset(int iu, int iv, int W) {        
 #define F3D_CODE_BAD 1u
 #define F3D_CODE_OTHER 2u
 #define F3D_PACKED_SMALL_WORDS 12             // packed 8-bit bins: alphabets up to 48 codes get the medium-LDS instance
+#ifndef F3D_PACKED_LARGE_WORDS
+#define F3D_PACKED_LARGE_WORDS 25            // ... up to 100 codes two points per lane with the view tables in global memory (3 blocks per CU)
+#endif
 #define F3D_BOOK_DWORDS 256                  // lut + inv + cmin of f3d_codebook, staged in LDS by k_fuse
 #define F3D_BIN32_MAX_CODES 12               // alphabets up to this many codes vote into dword bins (12 KiB of LDS per 256 points: 4 blocks per CU)
 
@@ -558,13 +561,24 @@ __device__ __forceinline__ bool finish_coded(unsigned nvalid, const uint32_t* hc
         const unsigned k3 = (c3 << 8) | 3u;
         best = best > k3 ? best : k3;
     }
+    // the other words, four bins at a time: the bytes of a word are split into two pairs of 16-bit lanes (count in the high byte, the
+    // word's index below it), v_pk_max_u16 keeps per byte position the highest count and among equal counts the highest word = the
+    // highest code = the smallest label; v_sad_u8 adds the four counts to the total.  6 instructions per word instead of 14.
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 me = {0, 0}, mo = {0, 0};
     for (int w = 1; w < words; ++w) {
         const unsigned x = hcol[w * F3D_BLOCK];
+        const unsigned tag = (unsigned)w * 0x00010001u;
+        sum = __builtin_amdgcn_sad_u8(x, 0u, sum);
+        const unsigned o = (x & 0xFF00FF00u) | tag, e = ((x << 8) & 0xFF00FF00u) | tag;
+        mo = __builtin_elementwise_max(mo, __builtin_bit_cast(u16x2, o));
+        me = __builtin_elementwise_max(me, __builtin_bit_cast(u16x2, e));
+    }
+    {
+        const unsigned cand[4] = {me.x, mo.x, me.y, mo.y};               // byte positions 0..3: (count << 8) | word
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned c = (x >> (8 * j)) & 0xFFu;
-            const unsigned key = (c << 8) | (unsigned)(4 * w + j);
-            sum += c;
+        for (unsigned j = 0; j < 4; ++j) {
+            const unsigned key = (cand[j] & 0xFF00u) | ((cand[j] & 0x3Fu) << 2) | j;
             best = best > key ? best : key;
         }
     }
@@ -698,7 +712,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     const int words = (ncodes + 3) >> 2;
     const int hdw = BIN32 ? ncodes : words;                               // histogram dwords per point
     extern __shared__ uint32_t lds_u32[];
-    // TLDS: the per-view constants of a 64-view group are staged in LDS; otherwise (the any-alphabet instance, whose histograms need the
+    // TLDS: the per-view constants of a 64-view group are staged in LDS; otherwise (the large-alphabet instances, whose histograms need the
     // room) they are read from the transposed global tables ctabT / vtabT
     float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes (+ image size) of one view group
     uint32_t* lutw = TLDS ? lds_u32 + 64 * F3D_CULL_ROW : lds_u32;        // lut[256], inv[256] (bytes), cmin[256] (uint16): F3D_BOOK_DWORDS
@@ -708,8 +722,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
     const uint8_t* inv = lut + 256;
     const int tid = threadIdx.x, lane = threadIdx.x & 63;
-    constexpr int TILE = F3D_BLOCK * PPL;                                 // PPL = 2 points per lane; 1 for alphabets whose histograms would
-                                                                          // otherwise leave room for a single block per CU (the second slot idles)
+    constexpr int TILE = F3D_BLOCK * PPL;                                 // PPL = points per lane: every instance in use has 2 (a one-point
+                                                                          // instance for huge histograms was measured slower than two points at 2 blocks per CU)
     const int npts = (int)n;                                              // n < 2^31 - TILE (checked by the launcher): 32-bit indices
     const int ntiles = (int)((n + TILE - 1) / TILE);
     const unsigned plane = (unsigned)f3d_coded_plane(H, W);               // bytes per view of the coded masks (V * plane < 2^32: launcher)
@@ -1357,7 +1371,7 @@ template <typename T, bool V, bool CARRY>
 static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* views_dev, int nviews, const uint8_t* masks, const uint8_t* cmasks,
                                 int h, int w, int nclasses, const f3d_filter_args& flt, double threshold, int64_t* classes, uint16_t* votes,
                                 int* err, const int32_t* perm, bool gather_xyz, unsigned int* todo_count, int32_t* todo,
-                                unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, void* tables, int mode, int grid, int grid1,
+                                unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, void* tables, int mode, int grid,
                                 int v0, int v1, uint32_t* carry, void* xyz_keep, hipStream_t s) {
     // CARRY: the fast kernel runs over the views [v0, v1) only and parks / resumes the vote bins in `carry`; the float64 tier and
     // the exact kernel follow the last chunk (v1 == nviews) and see every view.  Otherwise v0 = 0, v1 = nviews.
@@ -1371,7 +1385,7 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
         return hipErrorInvalidValue;                         // 32-bit point indices and mask offsets; filter list in device memory
     const dim3 g(grid), b(F3D_BLOCK), ge(fast ? 512 : grid);
     const int words_max = (nclasses + 1 + 2 + 3) >> 2;      // every label 0..nclasses present, plus the codes "no sample" and "rejected"
-    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2), lds_full = fuse_lds_bytes(words_max, 1, false);
+    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2), lds_full = fuse_lds_bytes(words_max, 2, false);
     float* ctabT = reinterpret_cast<float*>(tables);
     double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((cnv + 63) / 64) * 64 * 24 * sizeof(float));
     const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses);
@@ -1380,13 +1394,16 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
     if (fast) {
         const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
         auto ks = k_fuse<T, 2, V, true, false, true, CARRY>;     // dword bins: at most F3D_BIN32_MAX_CODES codes
-        // 8-bit bins, 4 per dword, 2 points per lane;  any alphabet: 1 point per lane, tables in global memory
+        // 8-bit bins, 4 per dword, 2 points per lane: <= 48 codes with the view tables in LDS; <= 100 codes / any alphabet with the tables in
+        // global memory and 25 / all bin words per point (3 / 2 blocks per CU)
         auto km2 = k_fuse<T, 2, V, false, false, true, CARRY>;
-        auto kf = k_fuse<T, 1, V, false, false, false, CARRY>;
-        if (!CARRY && wrap) { km2 = k_fuse<T, 2, V, false, true, true, false>; kf = k_fuse<T, 1, V, false, true, false, false>; }
-        if ((e = raise_lds(ks, lds_small)) != hipSuccess || (e = raise_lds(kf, lds_full)) != hipSuccess) return e;
-        // three instances are enqueued (dword bins for tiny alphabets; packed 8-bit bins with LDS for up to F3D_PACKED_SMALL_WORDS
-        // words, i.e. 48 codes; packed bins for any alphabet): LDS per block decides how many blocks a CU holds, and only the device
+        auto km3 = k_fuse<T, 2, V, false, false, false, CARRY>;
+        auto kf = km3;                                           // any alphabet: the same code with room for every bin (2 blocks per CU)
+        if (!CARRY && wrap) { km2 = k_fuse<T, 2, V, false, true, true, false>; km3 = kf = k_fuse<T, 2, V, false, true, false, false>; }
+        const size_t lds_large = fuse_lds_bytes(words_max < F3D_PACKED_LARGE_WORDS ? words_max : F3D_PACKED_LARGE_WORDS, 2, false);
+        if ((e = raise_lds(ks, lds_small)) != hipSuccess || (e = raise_lds(kf, lds_full > lds_large ? lds_full : lds_large)) != hipSuccess) return e;
+        // up to four instances are enqueued (dword bins for tiny alphabets; packed 8-bit bins for up to 48, up to 100 and for any number
+        // of codes): LDS per block decides how many blocks a CU holds, and only the device
         // knows how many labels the masks contain -- the code book says which instance runs, the others return at once
         const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2);
         hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
@@ -1395,9 +1412,13 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
             hipLaunchKernelGGL(km2, g, b, lds_mid, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
                                classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS,
                                ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
-        if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS) {
-            hipLaunchKernelGGL(kf, dim3(grid1), b, lds_full, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev,
-                               threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 256,
+        if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS)
+            hipLaunchKernelGGL(km3, g, b, lds_large, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
+                               classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 4 * F3D_PACKED_LARGE_WORDS,
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
+        if (nclasses + 3 > 4 * F3D_PACKED_LARGE_WORDS) {
+            hipLaunchKernelGGL(kf, g, b, lds_full, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev,
+                               threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_LARGE_WORDS + 1, 256,
                                ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
         }
         if (chunk_flags & 2) return hipGetLastError();       // more view chunks to come
@@ -1423,7 +1444,7 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
 }
 
 // Before f3d_launch_fuse, on any stream that is joined into its stream: the threshold table of the code book (segment_point) and the
-// transposed per-view tables of the views [v0, v1) the any-alphabet instance reads (tables: f3d_fuse_tables_bytes(nviews) of scratch).
+// transposed per-view tables of the views [v0, v1) the large-alphabet instances read (tables: f3d_fuse_tables_bytes(nviews) of scratch).
 hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold, hipStream_t s) {
     const int cnv = v1 - v0;
     if (cnv <= 0) return hipSuccess;
@@ -1447,17 +1468,16 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     unsigned int* todo2_count = todo_count + 1;
     int32_t* todo2 = todo + n;
     const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);      // bins of the exact kernel; the fast one uses 8 bits
-    const int64_t ntiles = (n + F3D_BLOCK * 2 - 1) / (F3D_BLOCK * 2);          // k_fuse: 2 points per lane ...
-    const int64_t ntiles1 = (n + F3D_BLOCK - 1) / F3D_BLOCK;                   // ... 1 in the any-alphabet instance
-    int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID), grid1 = (int)(ntiles1 < F3D_FUSE_GRID ? ntiles1 : F3D_FUSE_GRID);
-    grid = (grid + 7) & ~7; grid1 = (grid1 + 7) & ~7;        // the XCD-aware tile mapping needs a multiple of 8 blocks
+    const int64_t ntiles = (n + F3D_BLOCK * 2 - 1) / (F3D_BLOCK * 2);          // k_fuse: 2 points per lane
+    int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID);
+    grid = (grid + 7) & ~7;                                  // the XCD-aware tile mapping needs a multiple of 8 blocks
     if (carry && votes) return hipErrorInvalidValue;
     if (!carry) { v0 = 0; v1 = nviews; }
     if (cmasks && v0 == 0) {
         hipError_t e0 = hipMemsetAsync(todo_count, 0, 4 * sizeof(unsigned int), s);
         if (e0 != hipSuccess) return e0;
     }
-#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, grid1, v0, v1, carry, xyz_keep, s
+#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, v0, v1, carry, xyz_keep, s
     if (carry) return dtype == F3D_F64 ? launch_fuse_t<double, false, true>(F3D_ARGS) : launch_fuse_t<float, false, true>(F3D_ARGS);
     if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true, false>(F3D_ARGS) : launch_fuse_t<double, false, false>(F3D_ARGS);
     return votes ? launch_fuse_t<float, true, false>(F3D_ARGS) : launch_fuse_t<float, false, false>(F3D_ARGS);

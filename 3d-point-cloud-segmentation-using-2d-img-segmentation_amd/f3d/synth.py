@@ -72,6 +72,8 @@ def masks(V, h, w, kind='block64', seed=9012):
         return rng.integers(0, 134, (V, h, w), dtype=np.uint8)
     if kind == 'block64x40':                              # 40 labels: the packed-bin instance of the fused kernel
         alphabet = np.arange(0, 133, 133 // 40, dtype=np.uint8)[:40]
+    elif kind in ('block64x96', 'block64x100'):           # 96 / 100 labels: the large packed instance / the any-alphabet instance
+        alphabet = np.arange(0, int(kind[8:]), dtype=np.uint8)
     elif kind == 'block64':
         alphabet = ALPHABET
     else:

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument('--no-merge', action='store_true', help='skip the C5 bbox-merge leg (50M points, 4096 instances)')
     ap.add_argument('--views', type=int, default=64)
     ap.add_argument('--size', type=int, default=1024, help='mask width = height')
-    ap.add_argument('--masks', default='block64', choices=['block64', 'block64x40', 'iid'])
+    ap.add_argument('--masks', default='block64', choices=['block64', 'block64x40', 'block64x96', 'block64x100', 'iid'])
     ap.add_argument('--filter', action='store_true', help='segment with the reference default filter_classes=[86,114,115]')
     ap.add_argument('--f32', action='store_true', help='store xyz as float32 (12 B/point) instead of float64')
     ap.add_argument('--no-cpu-baseline', action='store_true')
