@@ -606,3 +606,16 @@ def test_view_chunked_call_deferred_points_errors_and_sequence(ctx):
         ctx.fuse_chunked_begin_dev(None, len(pts), 256, H, W, 133, None, None)
     ctx.synchronize()
     assert np.array_equal(cls.cpu().numpy(), _dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.0, 0))
+
+
+def test_fused_randomised_configurations(ctx):
+    """scripts/fused_fuzz.py: random scene / view count (incl. > 64 and > 255) / mask size / label alphabet (every k_fuse instance) /
+    threshold / filter / dtype / sort flag / chunk split -- labels and vote rows against the oracle, chunked against one-shot."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location('fused_fuzz', Path(__file__).resolve().parent.parent / 'scripts' / 'fused_fuzz.py')
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = np.random.default_rng(77)
+    for k in range(40):
+        fuzz.one_config(ctx, rng, k, verbose=False)
