@@ -229,7 +229,8 @@ f3d_ctx* f3d_ctx_create(int device) {
               hipMalloc((void**)&ctx->count_dev, sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&ctx->codebook, sizeof(f3d_codebook)) == hipSuccess &&
               hipMalloc((void**)&ctx->first_bad, sizeof(int)) == hipSuccess &&
-              hipMemset(ctx->dev_err, 0, sizeof(int)) == hipSuccess;
+              hipMemset(ctx->dev_err, 0, sizeof(int)) == hipSuccess &&
+              hipMemset(ctx->codebook, 0, sizeof(f3d_codebook)) == hipSuccess;       // (the presence set is kept zero between calls)
     if (!ok) {
         fail(nullptr, F3D_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
         f3d_ctx_destroy(ctx);
@@ -564,7 +565,7 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
         void* tm;                                                                               // grows on first use only
         if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &tm))) return rc;
         F3D_HIP(ctx, f3d_launch_code_masks(masks, (uint8_t*)tm, nviews, h, w, nclasses, fa, votes_u16 != nullptr, ctx->codebook, s));
-        F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, 0, nviews, tables, ctx->codebook, threshold, s));
+        F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, 0, nviews, tables, ctx->codebook, threshold, (unsigned int*)todo, s));
         cmasks = (const uint8_t*)tm;
     }
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,
@@ -651,7 +652,7 @@ int f3d_fuse_chunk_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n
     if ((rc = ensure(ctx, SLOT_FUSE_CARRY, f3d_fuse_carry_bytes(n, nclasses), &carry))) return rc;
     const size_t plane = f3d_coded_masks_bytes(1, h, w);
     F3D_HIP(ctx, f3d_launch_code_planes(masks + (size_t)v_begin * h * w, (uint8_t*)tm + (size_t)v_begin * plane, v_end - v_begin, h, w, ctx->codebook, s));
-    F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, v_begin, v_end, tables, ctx->codebook, threshold, s));
+    F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, v_begin, v_end, tables, ctx->codebook, threshold, v_begin == 0 ? (unsigned int*)todo : nullptr, s));
     F3D_HIP(ctx, f3d_launch_fuse(cxyz, dtype, n, views_dev, nviews, masks, (const uint8_t*)tm, h, w, nclasses, fa, threshold, classes, nullptr,
                                  ctx->dev_err, ctx->chunk.perm, cgather, (unsigned int*)todo, (int32_t*)((char*)todo + 16),
                                  ctx->codebook, tables, v_begin, v_end, (uint32_t*)carry, keep, s));

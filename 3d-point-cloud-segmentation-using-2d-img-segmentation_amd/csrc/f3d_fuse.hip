@@ -186,7 +186,12 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_mask_presence(const uint8_t* __re
 // the presence set as 256 bytes of 0 / 1 (to_bytes) or back (one block of 256 threads)
 __global__ __launch_bounds__(F3D_BLOCK) void k_presence_bytes(f3d_codebook* __restrict__ cb, uint8_t* __restrict__ bytes256, int to_bytes) {
     const unsigned l = threadIdx.x;
-    if (to_bytes) { bytes256[l] = (uint8_t)((cb->presence[l >> 5] >> (l & 31u)) & 1u); return; }
+    if (to_bytes) {
+        bytes256[l] = (uint8_t)((cb->presence[l >> 5] >> (l & 31u)) & 1u);
+        __syncthreads();
+        if (l < 8) cb->presence[l] = 0u;                          // consumed (see f3d_launch_mask_presence)
+        return;
+    }
     const unsigned long long m = __ballot(bytes256[l] != 0);
     if ((l & 63u) == 0u) { cb->presence[l >> 5] = (unsigned)m; cb->presence[(l >> 5) + 1] = (unsigned)(m >> 32); }
 }
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_code_lut(f3d_codebook* __restrict
     __shared__ unsigned pres[8];
     __shared__ int first_of[256];                                  // filter book: position of label l's first occurrence, -1 = not listed
     const unsigned l = threadIdx.x;
-    if (l < 8) pres[l] = book == 1 ? cb->presence[l] : 0xFFFFFFFFu;
+    if (l < 8) { pres[l] = book == 1 ? cb->presence[l] : 0xFFFFFFFFu; cb->presence[l] = 0u; }   // consumed (see f3d_launch_mask_presence)
     first_of[l] = -1;
     cb->inv[l] = 0;
     __syncthreads();
@@ -680,8 +685,12 @@ __device__ __forceinline__ void wave_box(float& lo0, float& hi0, float& lo1, flo
 // size; 15 doubles: M, t, mnorm), for the instance that cannot afford them in LDS: consecutive lanes read consecutive addresses
 __device__ __forceinline__ void threshold_table(f3d_codebook* __restrict__ cb, double threshold);
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_setup(const f3d_view* __restrict__ views, int nviews, float* __restrict__ ctabT,
-                                                           double* __restrict__ vtabT, f3d_codebook* __restrict__ cb, double threshold) {
-    if (blockIdx.x == 0) threshold_table(cb, threshold);      // ... and the call's threshold table (segment_point)
+                                                           double* __restrict__ vtabT, f3d_codebook* __restrict__ cb, double threshold,
+                                                           unsigned int* __restrict__ todo_count) {
+    if (blockIdx.x == 0) {
+        threshold_table(cb, threshold);                       // ... the call's threshold table (segment_point)
+        if (todo_count && threadIdx.x < 4) todo_count[threadIdx.x] = 0u;   // ... and empty deferred lists
+    }
     const int ngroups = (nviews + 63) >> 6;
     for (int k = blockIdx.x * F3D_BLOCK + threadIdx.x; k < ngroups * 64 * 39; k += gridDim.x * F3D_BLOCK) {
         const int v = k / 39, f = k - v * 39, g = v >> 6, l = v & 63;
@@ -1316,10 +1325,11 @@ static int pick_book(const f3d_filter_args& flt, bool want_votes) {
     return (distinct > 0) ? 2 : 1;
 }
 
-// labels present in `nbytes` mask bytes -> cb->presence (replaced, not accumulated)
+// labels present in `nbytes` mask bytes -> cb->presence.  The set is OR-ed into: it is zero when the context is created and whoever
+// consumes it (k_code_lut, k_presence_bytes) leaves it zero again -- one 5 us fill kernel less per call.  (A call that failed between
+// the two would leave a superset behind: a few unused vote bins in the next call, never a wrong label.)
 hipError_t f3d_launch_mask_presence(const uint8_t* src, int64_t nbytes, f3d_codebook* cb, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(cb->presence, 0, sizeof cb->presence, s);
-    if (e != hipSuccess || nbytes <= 0) return e;
+    if (nbytes <= 0) return hipSuccess;
     const bool vec = !((uintptr_t)src & 7);
     const dim3 g(grid_for(nbytes >> 3, F3D_BLOCK, 256 * 8)), b(F3D_BLOCK);
     if (vec) hipLaunchKernelGGL(k_mask_presence<true>, g, b, 0, s, src, nbytes, cb);
@@ -1445,12 +1455,14 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
 
 // Before f3d_launch_fuse, on any stream that is joined into its stream: the threshold table of the code book (segment_point) and the
 // transposed per-view tables of the views [v0, v1) the large-alphabet instances read (tables: f3d_fuse_tables_bytes(nviews) of scratch).
-hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold, hipStream_t s) {
+// todo_count (the 4 counters of the deferred lists; NULL for a later chunk of a view-chunked call) is zeroed here.
+hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold,
+                                 unsigned int* todo_count, hipStream_t s) {
     const int cnv = v1 - v0;
     if (cnv <= 0) return hipSuccess;
     float* ctabT = reinterpret_cast<float*>(tables);
     double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((cnv + 63) / 64) * 64 * 24 * sizeof(float));
-    hipLaunchKernelGGL(k_fuse_setup, dim3(8), dim3(F3D_BLOCK), 0, s, views_dev + v0, cnv, ctabT, vtabT, cb, threshold);
+    hipLaunchKernelGGL(k_fuse_setup, dim3(8), dim3(F3D_BLOCK), 0, s, views_dev + v0, cnv, ctabT, vtabT, cb, threshold, todo_count);
     return hipGetLastError();
 }
 
@@ -1473,10 +1485,7 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     grid = (grid + 7) & ~7;                                  // the XCD-aware tile mapping needs a multiple of 8 blocks
     if (carry && votes) return hipErrorInvalidValue;
     if (!carry) { v0 = 0; v1 = nviews; }
-    if (cmasks && v0 == 0) {
-        hipError_t e0 = hipMemsetAsync(todo_count, 0, 4 * sizeof(unsigned int), s);
-        if (e0 != hipSuccess) return e0;
-    }
+    // (with coded masks the counters of the deferred lists were zeroed by f3d_launch_fuse_setup, which must precede this call)
 #define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, v0, v1, carry, xyz_keep, s
     if (carry) return dtype == F3D_F64 ? launch_fuse_t<double, false, true>(F3D_ARGS) : launch_fuse_t<float, false, true>(F3D_ARGS);
     if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true, false>(F3D_ARGS) : launch_fuse_t<double, false, false>(F3D_ARGS);

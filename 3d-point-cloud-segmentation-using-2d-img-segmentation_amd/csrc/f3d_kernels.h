@@ -73,7 +73,8 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
                            unsigned int* todo_count, int32_t* todo, const f3d_codebook* cb, void* tables /* f3d_fuse_tables_bytes(nviews) */,
                            int v0, int v1, uint32_t* carry /* NULL: all views in one launch */, void* xyz_keep, hipStream_t s);
 size_t f3d_fuse_tables_bytes(int nviews);
-hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold, hipStream_t s);
+hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold,
+                                 unsigned int* todo_count /* zeroed; NULL: leave */, hipStream_t s);
 size_t f3d_fuse_carry_bytes(int64_t n, int nclasses);
 hipError_t f3d_launch_mask_presence(const uint8_t* src, int64_t nbytes, f3d_codebook* cb, hipStream_t s);
 hipError_t f3d_launch_presence_bytes(f3d_codebook* cb, uint8_t* bytes256, bool to_bytes, hipStream_t s);
