@@ -394,6 +394,14 @@ int f3d_rotate_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double q[4]
     return F3D_OK;
 }
 
+int f3d_rotate_f64_dev(f3d_ctx* ctx, const double* xyz, int64_t n, const double q[4], double* out, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || (n > 0 && (!xyz || !out)) || !q) return fail(ctx, F3D_ERR_INVALID, "rotate: bad arguments");
+    if (n == 0) return F3D_OK;
+    F3D_HIP(ctx, f3d_launch_rotate(xyz, n, q, out, pick(ctx, stream)));
+    return F3D_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // (f)#3 depth frame -> world points
 // ---------------------------------------------------------------------------------------------

@@ -74,6 +74,7 @@ def library():
         'f3d_frustum_data': (i32, [vp, dbl, dbl, vp, vp, i32, vp, vp, vp]),
         'f3d_views_build': (i32, [vp, dbl, dbl, vp, vp, i32, dbl, vp]),
         'f3d_rotate_f64': (i32, [vp, vp, i64, vp, vp]),
+        'f3d_rotate_f64_dev': (i32, [vp, vp, i64, vp, vp, vp]),
         'f3d_points2pixel_f64': (i32, [vp, vp, i64, vp, vp, vp, vp]),
         'f3d_points2pixel_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, vp, vp]),
         'f3d_inside_polyhedra_f64': (i32, [vp, vp, i64, vp, vp, i32, vp]),
@@ -581,6 +582,10 @@ class Context:
         f, nf = _filter(filter_classes)
         self._check(self._lib.f3d_fuse_chunk_dev(self._h, xyz_ptr, dtype, n, views_ptr, nviews, int(v_begin), int(v_end), masks_ptr, h, w,
                                                  int(nclasses), _ptr(f), nf, float(threshold), classes_ptr, int(flags), perm_ptr, stream))
+
+    def rotate_dev(self, xyz_ptr, n, q_wxyz, out_ptr, stream=None):
+        q = _f64(q_wxyz, (4,))
+        self._check(self._lib.f3d_rotate_f64_dev(self._h, xyz_ptr, n, _ptr(q), out_ptr, stream))
 
     def cloud_sort_cells_dev(self, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream=None):
         self._check(self._lib.f3d_cloud_sort_cells_dev(self._h, xyz_ptr, dtype, n, sorted_ptr, perm_ptr, stream))

@@ -461,6 +461,12 @@ def main():
         b = (xyz_b + 1) * nbig
         extras['inside_polyhedra (a4, 5 planes)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
                                                          bytes_per_point=xyz_b + 1, points=nbig)
+        if not args.f32:                                    # a1: the quaternion sandwich alone, same working set (24 B in + 24 B out)
+            rot = torch.empty_like(big)
+            tk = time_kernel(torch, lambda: ctx.rotate_dev(big.data_ptr(), nbig, views_np[0][49:53], rot.data_ptr(), stream.cuda_stream), 5, stream)
+            extras['rotate (a1)'] = dict(ms=round(tk * 1e3, 4), GBps=round(48 * nbig / tk / 1e9, 1), hbm_frac=round(48 * nbig / tk / 1e9 / HBM_PEAK_GBS, 4),
+                                         bytes_per_point=48, points=nbig)
+            del rot
         del big, ins
         ins = torch.empty(n, dtype=torch.uint8, device=dev)
         # (f)#3: one 1024x1024 16-bit depth frame -> world points

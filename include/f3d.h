@@ -139,6 +139,8 @@ int f3d_views_build(const double K[9], double w, double h, const double* q_wxyz,
 
 /* ---- a1: SpatQuadranion.rotate (RTAB_utils/spatQuad.py:7-28) ----------------------------- */
 int f3d_rotate_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double q_wxyz[4], double* out);
+/* device pointers (out may not alias xyz), enqueue only; the quaternion is read on the host at call time */
+int f3d_rotate_f64_dev(f3d_ctx* ctx, const double* xyz, int64_t n, const double q_wxyz[4], double* out, void* stream);
 
 /* ---- a2: points2pixel (Fusion3DSeg/camera_utils.py:9-26) -> int32 uv[2*n], row 0 = u ------ */
 int f3d_points2pixel_f64(f3d_ctx* ctx, const double* xyz, int64_t n, const double K[9],

@@ -619,3 +619,16 @@ def test_fused_randomised_configurations(ctx):
     rng = np.random.default_rng(77)
     for k in range(40):
         fuzz.one_config(ctx, rng, k, verbose=False)
+
+
+def test_rotate_dev_equals_host_pointer_rotate(ctx):
+    import torch
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(100_003, 3)) * 7.0
+    q = np.array([0.3, -0.4, 0.5, 0.7])                          # not normalised, like the reference's inverse quaternions
+    want = O.rotate(q, pts)
+    x = torch.from_numpy(pts).to(dev); out = torch.empty_like(x)
+    ctx.rotate_dev(x.data_ptr(), len(pts), q, out.data_ptr(), None)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(ctx.rotate(pts, q), want)
