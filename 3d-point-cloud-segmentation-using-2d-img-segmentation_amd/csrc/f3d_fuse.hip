@@ -864,12 +864,14 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             const int vj = 64 * g + lane;
             bool box_out = false, box_in = true, own_image = false;
             float pb0 = 0.f, pb1 = 0.f, pb2 = 0.f, pb3 = 0.f, pb4 = 0.f, pmarg = 0.f;    // (B): n . (c - plane point) per plane, margin
+            unsigned pneed = 0u;                                                         // (B): the planes that need a per-point test at all
             if (vj < nviews) {
                 // field f of this lane's view: LDS row (odd stride) or the transposed global table
                 const float* rowp = TLDS ? ctab + lane * F3D_CULL_ROW : ctabT + (size_t)g * 24 * 64 + lane;
                 auto rowf = [&](int f) { return TLDS ? rowp[f] : rowp[f * 64]; };
                 const float marg = 2.0f * __builtin_fmaf(rowf(20), ps_box, rowf(21));
                 float bmax = 0.f, smax = 0.f, base[F3D_NPLANES];
+                unsigned need = 0u;
 #pragma unroll
                 for (int m = 0; m < F3D_NPLANES; ++m) {
                     const float n0 = rowf(3 * m), n1 = rowf(3 * m + 1), n2 = rowf(3 * m + 2);
@@ -877,12 +879,14 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     const float spread = __builtin_fmaf(fabsf(n0), e0, __builtin_fmaf(fabsf(n1), e1, fabsf(n2) * e2));
                     box_out = box_out | (base[m] + spread < -marg);
                     box_in = box_in & (base[m] - spread > marg);
+                    need |= (base[m] - spread > marg) ? 0u : (1u << m);         // planes the box is not entirely in front of
                     bmax = fmaxf(bmax, fabsf(base[m])); smax = fmaxf(smax, spread);
                 }
                 // offset-form cull of a mixed view: a = base + n32 . d.  base itself is the float32 world-coordinate value, off the
                 // real n . (c - pp) by at most marg / 2 (that is what marg bounds); on top of it the float32 offset arithmetic:
                 // 2^-24 (4 |base| + 5 sum |n_j| E_j).
                 pb0 = base[0]; pb1 = base[1]; pb2 = base[2]; pb3 = base[3]; pb4 = base[4];
+                pneed = need;
                 pmarg = 0.5f * marg + 1.01f * (float)F3D_U24 * (4.0f * bmax + 5.0f * smax);
                 own_image = (int)(rowf(22) == Wf) & (int)(rowf(23) == Hf);  // the frustum was built for this mask size: inside the planes = inside the image
             }
@@ -970,17 +974,22 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #pragma unroll
                 for (int m = 0; m < F3D_NPLANES; ++m) { asm volatile("" : "+s"(nn[m][0])); asm volatile("" : "+s"(nn[m][1])); asm volatile("" : "+s"(nn[m][2])); }
 #define F3D_RL1(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), bit))
-                const float bb[F3D_NPLANES] = {F3D_RL1(pb0), F3D_RL1(pb1), F3D_RL1(pb2), F3D_RL1(pb3), F3D_RL1(pb4)};
                 const float mg = F3D_RL1(pmarg);
-#undef F3D_RL1
+                // only the planes the wave's box straddles are tested per point (usually one or two of the five): the box is entirely in
+                // front of the others, by the same margin that makes a view a whole-wave view
+                const unsigned need = (unsigned)__builtin_amdgcn_readlane((int)pneed, bit);
+                const float* pbs[F3D_NPLANES] = {&pb0, &pb1, &pb2, &pb3, &pb4};
                 const bool has_row = (row_m >> bit) & 1ull;  // wave-uniform
                 bool maybe[2] = {true, true}, sure[2] = {true, true};
 #pragma unroll
                 for (int m = 0; m < F3D_NPLANES; ++m) {
-                    const f32x2 a = F3D_FMA2(splat2(nn[m][0]), DX, F3D_FMA2(splat2(nn[m][1]), DY, F3D_FMA2(splat2(nn[m][2]), DZ, splat2(bb[m]))));
+                    if (!((need >> m) & 1u)) continue;       // wave-uniform: a scalar branch
+                    const float bbm = F3D_RL1(*pbs[m]);
+                    const f32x2 a = F3D_FMA2(splat2(nn[m][0]), DX, F3D_FMA2(splat2(nn[m][1]), DY, F3D_FMA2(splat2(nn[m][2]), DZ, splat2(bbm))));
                     maybe[0] = maybe[0] & (a.x > -mg); sure[0] = sure[0] & (a.x > mg);
                     maybe[1] = maybe[1] & (a.y > -mg); sure[1] = sure[1] & (a.y > mg);
                 }
+#undef F3D_RL1
                 unsigned off[2] = {0u, 0u};
                 if (has_row) {
                     centre_row r = read_row(mine, bit);
