@@ -13,6 +13,14 @@ from oracle import np_ref as O
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (a fixed rendezvous port can still be held by an earlier run's socket)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 def _scene(n=50_000):
     sc = synth.scene('C1', n=n)
     views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
@@ -142,7 +150,7 @@ def test_two_ranks_label_their_shards_with_the_hip_path(tmp_path):
     equal to the single-process HIP result and to the oracle."""
     import torch.multiprocessing as mp
     n = 40_001
-    mp.spawn(_rank_labels, args=(2, 29533, n, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank_labels, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
     sc, views = _scene(n)
     single = f3d.default_context().project_vote_argmax(sc['points'], views, sc['masks'], 133, 0.0, None)
     for r in range(2):
@@ -187,7 +195,7 @@ def _rank_overlap(rank, world, port, n, nchunks, out_dir):
 def test_two_ranks_overlap_the_mask_exchange_inside_the_step(tmp_path):
     import torch.multiprocessing as mp
     n, V = 30_001, 16
-    mp.spawn(_rank_overlap, args=(2, 29537, n, 4, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_rank_overlap, args=(2, _free_port(), n, 4, str(tmp_path)), nprocs=2, join=True)
     sc = synth.scene('C1', n=n)
     q, t = synth.ring_views(V)
     masks = synth.masks(V, sc['h'], sc['w'], 'block64x40')
