@@ -233,16 +233,16 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_vote_uv2pt_batch(const int32_t* _
                                                                  unsigned long long* __restrict__ table, uint64_t table_mask, unsigned gen,
                                                                  int frame0, const int* __restrict__ first_bad, int* __restrict__ err) {
     __shared__ unsigned long long lset[F3D_VOTE_LDS_SLOTS];
-    if (*err & F3D_DEVERR_VOTE) return;                               // an earlier, untaken IndexError: nothing is written any more
+    // An earlier, untaken IndexError: nothing is written any more.  The bit is only ever set BETWEEN vote launches (k_vote_batch_flag):
+    // when blocks of this very launch set it, blocks that started later returned here and dropped their share of the frames before
+    // the offending one (an intermittent wrong count, found by running the suite repeatedly).
+    if (*err & F3D_DEVERR_VOTE) return;
     const int fb = *first_bad;
     const int tiles = tiles_x * tiles_y;
     const int64_t hw = (int64_t)h * w;
     for (int64_t b = blockIdx.x; b < (int64_t)nframes * tiles; b += gridDim.x) {
         const int f = (int)(b / tiles), t = (int)(b - (int64_t)f * tiles);
-        if (frame0 + f >= fb) {                                       // the reference raised at frame fb: this frame never ran
-            if (frame0 + f == fb && t == 0 && threadIdx.x == 0) atomicOr(err, F3D_DEVERR_VOTE);
-            continue;
-        }
+        if (frame0 + f >= fb) continue;                               // the reference raised at frame fb: this frame never ran
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         for (int k = threadIdx.x; k < F3D_VOTE_LDS_SLOTS; k += F3D_BLOCK) lset[k] = F3D_VOTE_EMPTY;
         __syncthreads();
@@ -438,6 +438,11 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_relabel(int64_t* __restrict__ ids
 
 __global__ void k_clear_error_bits(int* err, int bits) { atomicAnd(err, ~bits); }
 
+// after a batched vote launch: a frame of the batch had an out-of-range index -> record the IndexError
+__global__ void k_vote_batch_flag(const int* __restrict__ first_bad, int* __restrict__ err) {
+    if (*first_bad != 0x7f7f7f7f) atomicOr(err, F3D_DEVERR_VOTE);
+}
+
 inline int grid_for(int64_t n, int per_block, int cap) {
     int64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -535,6 +540,7 @@ hipError_t f3d_launch_vote_uv2pt_batch(const int32_t* luts, const uint8_t* masks
     const int64_t blocks = (int64_t)nframes * tx * ty;
     hipLaunchKernelGGL(k_vote_uv2pt_batch, dim3((unsigned)(blocks < 1048576 ? blocks : 1048576)), dim3(F3D_BLOCK), 0, s, luts, masks, nframes, h, w, tx, ty,
                        votes, npts, ncols, table, (uint64_t)(table_slots - 1), gen, frame0, first_bad, err);
+    hipLaunchKernelGGL(k_vote_batch_flag, dim3(1), dim3(1), 0, s, first_bad, err);
     return hipGetLastError();
 }
 
