@@ -647,3 +647,21 @@ def test_rotate_dev_equals_host_pointer_rotate(ctx):
     ctx.rotate_dev(x.data_ptr(), len(pts), q, out.data_ptr(), None)
     ctx.synchronize()
     assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(ctx.rotate(pts, q), want)
+
+
+def test_vote_segment_merge_randomised_configurations(ctx):
+    """scripts/aux_fuzz.py: batched vote (offending frames, negative and duplicate lookups), segment_votes (thresholds, filter lists) and
+    merge_bb (random blob scenes with and without the inner-hull prefilter) against the oracle."""
+    import contextlib
+    import importlib.util
+    import io
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location('aux_fuzz', Path(__file__).resolve().parent.parent / 'scripts' / 'aux_fuzz.py')
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rng = np.random.default_rng(31)
+    for k in range(60):
+        fuzz.vote_config(ctx, rng)
+        if k % 6 == 0:
+            with contextlib.redirect_stdout(io.StringIO()):
+                fuzz.merge_config(rng)
