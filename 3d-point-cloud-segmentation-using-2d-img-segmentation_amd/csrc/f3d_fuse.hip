@@ -533,9 +533,12 @@ __device__ __forceinline__ void finish_bin32(const uint32_t* hcol, int ncodes, c
     }
 }
 
-template <bool WRAP>
+// GUARD: code 0 ("no sample") adds nothing.  A point casts more votes than there are views -- placeholders of the software pipeline (two per
+// 64-view group and one per odd chunk), padding slots, the final pend vote: up to nviews + 3 ngroups + 2 -- so from ~240 views on
+// byte 0 of word 0 could carry into byte 1, the rejected-label bin (a spurious IndexError and a total off by one).
+template <bool GUARD>
 __device__ __forceinline__ void vote_coded(unsigned& nvalid, uint32_t* hcol, unsigned b) {
-    if (WRAP) {
+    if (GUARD) {
         const unsigned one = b < 1u ? b : 1u;                                      // 0 for F3D_CODE_NONE
         nvalid += one;
         atomicAdd(&hcol[(b >> 2) * F3D_BLOCK], one << ((b & 3u) * 8u));
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
         auto vote = [&](int q, unsigned b) {
             if (q >= PPL) return;
             if (BIN32) vote_bin32(q ? hcol1 : hcol0, b);
-            else vote_coded<WRAP>(nvalid[q], q ? hcol1 : hcol0, b);
+            else vote_coded<WRAP || CARRY>(nvalid[q], q ? hcol1 : hcol0, b);   // a chunk of a chunked call is guarded too (any number of views per chunk)
         };
 
         for (int g = 0; g < ngroups; ++g) {
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     uint32_t x = 0u;
                     if (BIN32) {
 #pragma unroll
-                        for (int b4 = 0; b4 < 4; ++b4) if (4 * wd + b4 < ncodes) x |= hc[(4 * wd + b4) * F3D_BLOCK] << (8 * b4);
+                        for (int b4 = 0; b4 < 4; ++b4) if (4 * wd + b4 < ncodes) x |= (hc[(4 * wd + b4) * F3D_BLOCK] & 0xFFu) << (8 * b4);   // (the "no sample" dword may exceed 255)
                     } else {
                         x = hc[wd * F3D_BLOCK];
                     }
@@ -1411,7 +1414,9 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
     if (lds_exact > 160 * 1024 || lds_full > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e;
     if (fast) {
-        const bool wrap = nviews > 255;                      // an 8-bit vote bin can wrap: the guarded vote
+        // the guarded vote: an 8-bit bin of a real code can wrap (more than 255 views), or the "no sample" byte could (a point casts up to
+        // nviews + 3 ngroups + 2 votes, placeholders included: from ~240 views on)
+        const bool wrap = nviews + 3 * ((nviews + 63) / 64) + 2 > 255;
         auto ks = k_fuse<T, 2, V, true, false, true, CARRY>;     // dword bins: at most F3D_BIN32_MAX_CODES codes
         // 8-bit bins, 4 per dword, 2 points per lane: <= 48 codes with the view tables in LDS; <= 100 codes / any alphabet with the tables in
         // global memory and 25 / all bin words per point (3 / 2 blocks per CU)

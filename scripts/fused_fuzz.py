@@ -21,7 +21,7 @@ def one_config(ctx, rng, k, verbose=True):
     import torch
     dev = torch.device('cuda', 0)
     n = int(rng.choice([1, 63, 129, 700, 5_000, 40_000, 150_000, 400_000]))
-    V = int(rng.choice([1, 2, 7, 16, 33, 64, 65, 100, 130, 256, 300]))
+    V = int(rng.choice([1, 2, 7, 16, 33, 64, 65, 100, 130, 240, 247, 255, 256, 300]))   # 240..255: the 8-bit "no sample" byte boundary
     if V > 130:
         n = min(n, 40_000)
     W = int(rng.choice([64, 100, 333, 512, 640, 1001])); H = int(rng.choice([48, 100, 240, 512, 777]))

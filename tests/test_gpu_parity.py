@@ -111,6 +111,31 @@ def test_fused_forward_many_views_uint16_bins(ctx):
     assert np.array_equal(ctx.project_vote_argmax(pts, views, masks, 133, 0.5, None), want)
 
 
+@pytest.mark.parametrize('V', [240, 247, 255])
+def test_fused_forward_view_counts_at_the_8bit_boundary(ctx, V):
+    """A point casts more votes than there are views (placeholders of the software pipeline, padding slots): with packed 8-bit
+    bins the "no sample" byte must not carry into the rejected-label bin.  iid masks (the packed instances),
+    n not a multiple of the 128-point wave tile, a camera ring that leaves most points with few hits; one-shot and as ONE chunk of a
+    chunked call (the CARRY instance), both against the oracle."""
+    h = w = 96
+    K = np.array([[70., 0, 48], [0, 70., 48], [0, 0, 1]])
+    q, t = synth.ring_views(V)
+    pts = synth.cloud(20_037, seed=V)
+    rng = np.random.default_rng(V)
+    views = f3d.views_build(K, w, h, q, t, 3.0)                              # short frusta: most (point, view) pairs miss
+    for nlab in (134, 40):                                                   # any-alphabet and 48-code packed instances
+        masks = rng.choice(134, nlab, replace=False).astype(np.uint8)[rng.integers(0, nlab, (V, h, w))]
+        sub = rng.choice(len(pts), 2500, replace=False)
+        want, wv = O.project_vote_argmax(pts[sub], K, q, t, masks, 3.0, 133, 0.0, None, return_votes=True)
+        got = _dev_fuse(ctx, pts, views, masks, None, 0.0, f3d.FUSE_SORT)
+        assert np.array_equal(got[sub], want)
+        assert (wv.sum(1) <= 8).mean() > 0.05                                # points with few hits exist: their byte 0 is the one at risk
+        one_chunk = _dev_fuse_chunked(ctx, pts, views, masks, None, 0.0, f3d.FUSE_SORT, [0, V])
+        assert np.array_equal(one_chunk, got)
+        two = _dev_fuse_chunked(ctx, pts, views, masks, None, 0.0, 0, [0, V - 3, V])
+        assert np.array_equal(two, got)
+
+
 def test_fused_forward_edge_cases(ctx):
     sc = synth.scene('C1', n=1000)
     views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
