@@ -880,7 +880,16 @@ int f3d_sem_logits_to_mask_dev(f3d_ctx* ctx, const float* sem, int c, int64_t hw
     int rc = enter(ctx); if (rc) return rc;
     if (c <= 0 || c > 256 || hw < 0 || low_label < 0 || low_label > 255 || (hw > 0 && (!sem || !mask)))
         return fail(ctx, F3D_ERR_INVALID, "sem_logits_to_mask: bad arguments (1 <= c <= 256)");
-    F3D_HIP(ctx, f3d_launch_sem_to_mask(sem, c, hw, conf, low_label, mask, pick(ctx, stream)));
+    F3D_HIP(ctx, f3d_launch_sem_to_mask(sem, 1, c, hw, conf, low_label, mask, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_sem_logits_to_masks_dev(f3d_ctx* ctx, const float* sem, int nimg, int c, int64_t hw, float conf, int low_label, uint8_t* masks,
+                                void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (nimg < 0 || nimg > 65535 || c <= 0 || c > 256 || hw < 0 || low_label < 0 || low_label > 255 || (nimg > 0 && hw > 0 && (!sem || !masks)))
+        return fail(ctx, F3D_ERR_INVALID, "sem_logits_to_masks: bad arguments (1 <= c <= 256, at most 65535 images per call)");
+    F3D_HIP(ctx, f3d_launch_sem_to_mask(sem, nimg, c, hw, conf, low_label, masks, pick(ctx, stream)));
     return F3D_OK;
 }
 

@@ -306,10 +306,13 @@ __device__ __forceinline__ void sem_update(float x, int c, float& m, int& mi, fl
     mi = up ? c : mi;
 }
 
+// blockIdx.y = image of a batch: sem [B][C][hw] -> mask [B][hw] (consecutive planes of the caller's [V,H,W] mask tensor)
 template <bool VEC4>
 __global__ __launch_bounds__(F3D_BLOCK) void k_sem_to_mask(const float* __restrict__ sem, int C, int64_t hw, float conf,
                                                             int low_label, uint8_t* __restrict__ mask) {
     constexpr int PX = VEC4 ? 4 : 1;
+    sem += (size_t)blockIdx.y * (size_t)C * (size_t)hw;
+    mask += (size_t)blockIdx.y * (size_t)hw;
     const int64_t ngroups = (hw + PX - 1) / PX;
     for (int64_t gidx = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; gidx < ngroups; gidx += (int64_t)gridDim.x * F3D_BLOCK) {
         const int64_t px0 = gidx * PX;
@@ -544,12 +547,14 @@ hipError_t f3d_launch_vote_uv2pt_batch(const int32_t* luts, const uint8_t* masks
     return hipGetLastError();
 }
 
-hipError_t f3d_launch_sem_to_mask(const float* sem, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s) {
-    if (hw <= 0) return hipSuccess;
+hipError_t f3d_launch_sem_to_mask(const float* sem, int nimg, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s) {
+    if (hw <= 0 || nimg <= 0) return hipSuccess;
+    if (nimg > 65535) return hipErrorInvalidValue;
     const bool vec4 = (hw % 4 == 0) && ((reinterpret_cast<uintptr_t>(sem) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
     const dim3 b(F3D_BLOCK);
-    if (vec4) hipLaunchKernelGGL(k_sem_to_mask<true>, dim3(grid_for(hw / 4, F3D_BLOCK, F3D_GRID_CAP)), b, 0, s, sem, c, hw, conf, low_label, mask);
-    else hipLaunchKernelGGL(k_sem_to_mask<false>, dim3(grid_for(hw, F3D_BLOCK, F3D_GRID_CAP)), b, 0, s, sem, c, hw, conf, low_label, mask);
+    const int cap = nimg > 1 ? (F3D_GRID_CAP + nimg - 1) / nimg : F3D_GRID_CAP;
+    if (vec4) hipLaunchKernelGGL(k_sem_to_mask<true>, dim3(grid_for(hw / 4, F3D_BLOCK, cap), nimg), b, 0, s, sem, c, hw, conf, low_label, mask);
+    else hipLaunchKernelGGL(k_sem_to_mask<false>, dim3(grid_for(hw, F3D_BLOCK, cap), nimg), b, 0, s, sem, c, hw, conf, low_label, mask);
     return hipGetLastError();
 }
 

@@ -98,6 +98,7 @@ def library():
         'f3d_segment_votes_dev': (i32, [vp, vp, i64, i32, i32, dbl, vp, i32, vp, vp]),
         'f3d_sem_logits_to_mask': (i32, [vp, vp, i32, i64, flt, i32, vp]),
         'f3d_sem_logits_to_mask_dev': (i32, [vp, vp, i32, i64, flt, i32, vp, vp]),
+        'f3d_sem_logits_to_masks_dev': (i32, [vp, vp, i32, i32, i64, flt, i32, vp, vp]),
         'f3d_points_in_obb': (i32, [vp, vp, i32, i64, vp, i32, vp, vp]),
         'f3d_points_in_obb_dev': (i32, [vp, vp, i32, i64, vp, i32, vp, vp, vp]),
         'f3d_group_by_id': (i32, [vp, vp, i64, i64, vp, vp]),
@@ -624,6 +625,10 @@ class Context:
 
     def sem_logits_to_mask_dev(self, sem_ptr, c, hw, conf, low_label, mask_ptr, stream=None):
         self._check(self._lib.f3d_sem_logits_to_mask_dev(self._h, sem_ptr, c, hw, float(conf or 0.0), int(low_label), mask_ptr, stream))
+
+    def sem_logits_to_masks_dev(self, sem_ptr, nimg, c, hw, conf, low_label, masks_ptr, stream=None):
+        """nimg images of logits [nimg, c, hw] -> nimg consecutive planes at masks_ptr (device-resident hand-off, no sync)."""
+        self._check(self._lib.f3d_sem_logits_to_masks_dev(self._h, sem_ptr, int(nimg), c, hw, float(conf or 0.0), int(low_label), masks_ptr, stream))
 
     def points_in_obb_dev(self, xyz_ptr, dtype, n, boxes, bits_ptr, cooc_ptr, stream=None):
         b = _f64(boxes)

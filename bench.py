@@ -62,6 +62,18 @@ def parse():
     return ap.parse_args()
 
 
+def fuse_instance(labels_present, flt):
+    """Which k_fuse instance the code book selects (csrc/f3d_fuse.hip: launch_fuse_t): codes = labels + 2 (no sample, rejected)."""
+    codes = (3 + len(set(flt))) if (flt and len(flt) <= 8) else labels_present + 2
+    if codes <= 12:
+        return f'{codes} codes: dword bins (<= 12 codes)'
+    if codes <= 48:
+        return f'{codes} codes: packed 8-bit bins, view tables in LDS (<= 48 codes)'
+    if codes <= 100:
+        return f'{codes} codes: packed 8-bit bins, view tables in global memory (<= 100 codes)'
+    return f'{codes} codes: packed 8-bit bins, any alphabet'
+
+
 def algorithmic_bytes(n, v, h, w, xyz_bytes):
     """xyz read once + masks read once + int64 classes written + view records."""
     return xyz_bytes * n + v * h * w + 8 * n + 704 * v
@@ -89,13 +101,19 @@ def cpu_baseline(sample, views_n, size, mask_kind, filter_classes):
     pts = synth.cloud(sample)
     masks = synth.masks(views_n, size, size, mask_kind)
     out = np.empty(sample, np.int64)
-    t0 = time.perf_counter()
+    out0 = np.empty(sample, np.int64)
+    votes16 = np.empty((sample, 134), np.uint16)               # kept for the vote-row comparison (counts <= 64)
+    dt = 0.0
     for s0 in range(0, sample, 250_000):
-        out[s0:s0 + 250_000] = O.project_vote_argmax(pts[s0:s0 + 250_000], K, q, t, masks, 10.0, 133, 0.5, filter_classes)
-    dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        votes = O.forward_votes(pts[s0:s0 + 250_000], K, q, t, masks, 10.0, ncols=134)
+        out[s0:s0 + 250_000] = O.segment(votes, 133, 0.5, filter_classes)
+        dt += time.perf_counter() - t0                         # the timed part = one pass of the path at the bench's setting
+        out0[s0:s0 + 250_000] = O.segment(votes, 133, 0.0, filter_classes)      # threshold 0: every sampled point carries a real label
+        votes16[s0:s0 + 250_000] = votes
     return dict(value=round(sample / dt, 1), unit='points/s', cores=1, kind='port',
                 sample=f'{sample} points x {views_n} views in {dt:.1f} s, one NumPy process ({os.cpu_count()} host cpus visible, '
-                       f'elementwise NumPy only -> 1 core); the path is linear in N'), out, pts, masks, (K, q, t)
+                       f'elementwise NumPy only -> 1 core); the path is linear in N'), out, pts, masks, (K, q, t), out0, votes16
 
 
 def merge_leg(local):
@@ -151,6 +169,148 @@ def merge_leg(local):
                                          f'instances of the same recipe; its cost grows like B^2 N / 8, i.e. ~{dtc * (B / Bs) ** 2 * (n / ns) / 3600:.0f} h '
                                          f'extrapolated to the full C5 shape',
                                   same_result_as_hip_on_sample=same))
+
+
+def end_to_end_leg(torch, ctx, dev, stream, xyz, dtype, n, views, views_np, V, S, flt, flags, perm_ptr, steps=3):
+    """BASELINE config 3 as written: "end-to-end incl. the 2D backbone on PyTorch-ROCm".  Per step: V frames through a
+    PyTorch-ROCm network (a STAND-IN with OneFormer's contract, f3d/standin.py -- OneFormer itself is absent), the network's
+    logits -> mask kernel writing plane j of ONE uint8 [V,H,W] device tensor (f3d_sem_logits_to_masks_dev; no PNG, no D2H, no
+    synchronisation), and the fused call reading that tensor.  torch's sync debug mode is armed ('error') over the steps: any
+    synchronising torch call (.cpu(), .item(), ...) inside would raise."""
+    import get2DSeg
+    from f3d.standin import StandInSegNet, synthetic_frames
+    from oracle import np_ref as O
+    from f3d import synth
+    B = 8
+    net = StandInSegNet().to(dev).eval()
+    frames = synthetic_frames(V, S, S, dev)
+    masks = torch.empty((V, S, S), dtype=torch.uint8, device=dev)
+    classes = torch.empty(n, dtype=torch.int64, device=dev)
+    nb = (V + B - 1) // B
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nb)]
+    ev_f = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def step(timed=False):
+        for k, j in enumerate(range(0, V, B)):
+            if timed:
+                ev[k][0].record(stream)
+            sem = net(frames[j:j + B])
+            if timed:
+                ev[k][1].record(stream)
+            get2DSeg.sem_to_mask_device(sem, masks[j:j + B], 0.017)
+            if timed:
+                ev[k][2].record(stream)
+        if timed:
+            ev_f[0].record(stream)
+        ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, masks.data_ptr(), S, S, 133, 0.5, flt,
+                                    classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
+        if timed:
+            ev_f[1].record(stream)
+
+    step(); step()                                            # warm-up (GEMM selection, allocator)
+    torch.cuda.synchronize()
+
+    def arm(mode):
+        try:
+            torch.cuda.set_sync_debug_mode(mode)
+            return True
+        except Exception:                                     # not supported by this torch build: the property is then unchecked
+            return False
+    armed = arm('error')
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        arm('default')
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        arm('error')
+        step(timed=True)
+    finally:
+        arm('default')
+    torch.cuda.synchronize()
+    t_net = sum(e[0].elapsed_time(e[1]) for e in ev)
+    t_mask = sum(e[1].elapsed_time(e[2]) for e in ev)
+    t_fuse = ev_f[0].elapsed_time(ev_f[1])
+    ctx.take_device_error(stream.cuda_stream)
+    # parity: (1) the masks against the reference's own statements (get2DSeg.py:110-118) in torch on the same logits, outside
+    # the 1e-5 relative band around the threshold that sem_mask.npz's rule states; (2) labels of a sample against the oracle
+    # fed the masks the device produced
+    sem = net(frames[:2])
+    want = sem.argmax(dim=1)
+    pmax = torch.amax(torch.nn.Softmax(dim=1)(sem), dim=1)
+    want[pmax < 0.017] = 133
+    clear = (pmax.double() - 0.017).abs() > 1e-5 * 0.017
+    got = torch.empty((2, S, S), dtype=torch.uint8, device=dev)
+    get2DSeg.sem_to_mask_device(sem, got, 0.017)
+    masks_ok = bool(torch.equal(got[clear].long(), want[clear]) and float(clear.float().mean()) > 0.9999)
+    masks_np = masks.cpu().numpy()
+    K = np.array([[800., 0, S / 2], [0, 800., S / 2], [0, 0, 1]])
+    q, t = synth.ring_views(V)
+    sub = np.random.default_rng(11).choice(n, min(n, 100_000), replace=False)
+    pts = xyz[torch.from_numpy(sub).to(dev)].double().cpu().numpy()
+    votes = O.forward_votes(pts, K, q, t, masks_np, 10.0, ncols=134)
+    want_cls, want_cls0 = O.segment(votes, 133, 0.5, flt), O.segment(votes, 133, 0.0, flt)
+    got_cls = classes.cpu().numpy()[sub]
+    ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, masks.data_ptr(), S, S, 133, 0.0, flt,
+                                classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)   # threshold 0: real labels
+    stream.synchronize()
+    got_cls0 = classes.cpu().numpy()[sub]
+    return dict(workload=f'C3 end-to-end: {V} frames {S}x{S} -> stand-in 2D network (PyTorch-ROCm, bf16 GEMMs; NOT OneFormer, which is absent: '
+                         f'f3d/standin.py) -> logits [133,{S},{S}] f32 -> f3d_sem_logits_to_masks_dev -> uint8 [V,H,W] device tensor -> '
+                         f'f3d_project_vote_argmax_dev over {n} points',
+                ms_per_step=round(dt * 1e3, 3), points_per_s=round(n / dt, 1),
+                stage_ms=dict(network_standin=round(t_net, 3), logits_to_mask=round(t_mask, 3), fused_3d=round(t_fuse, 3)),
+                frames_per_batch=B, png_round_trip=False,
+                no_host_sync=('torch.cuda.set_sync_debug_mode("error") armed over the steps: no synchronising torch call, no D2H; the library calls are _dev entry points (enqueue only)'
+                              if armed else 'unchecked: torch.cuda.set_sync_debug_mode unavailable'),
+                masks_equal_reference_statements=masks_ok, mask_labels_present=int(len(np.unique(masks_np))),
+                low_confidence_pixel_fraction=round(float((masks_np == 133).mean()), 4),
+                labels_equal_oracle_on_sample=bool(np.array_equal(got_cls, want_cls) and np.array_equal(got_cls0, want_cls0)), sample_points=len(sub),
+                real_label_fraction=dict(threshold_0p5=round(float((want_cls != 133).mean()), 4), threshold_0p0=round(float((want_cls0 != 133).mean()), 4)))
+
+
+def variants_leg(torch, ctx, dev, stream, xyz, dtype, n, views, V, S, flags, perm_ptr, steps=5):
+    """The other SURVEY 8(d) workloads through the same timed step (caller-order cloud, in-step sort): mask variants iid (134 labels
+    in every tile: the any-alphabet instance of k_fuse) and a 40-label blocky alphabet (packed 8-bit bins), and the reference's
+    default filter list; ms per step each."""
+    from f3d import synth
+    out = {}
+    classes = torch.empty(n, dtype=torch.int64, device=dev)
+    for name, kind, flt in [('iid', 'iid', None), ('block64x40', 'block64x40', None), ('block64x100', 'block64x100', None),
+                            ('block64_filter_86_114_115', 'block64', [86, 114, 115])]:
+        m = torch.from_numpy(synth.masks(V, S, S, kind)).to(dev)
+
+        def fn():
+            ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, m.data_ptr(), S, S, 133, 0.5, flt,
+                                        classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
+        tk = time_kernel(torch, fn, steps, stream)
+        ctx.take_device_error(stream.cuda_stream)
+        out[name] = dict(ms_per_step=round(tk * 1e3, 4), points_per_s=round(n / tk, 1), labels_in_masks=int(len(np.unique(m[:4].cpu().numpy()))),
+                         filter_classes=flt)
+        del m
+    return out
+
+
+def c1_leg(local):
+    """C1 (100k points x 4 views, 512x512) is CPU-timed in full -- the oracle, one process -- next to the
+    same inputs through the HIP path (host-pointer call: upload and download inside its time)."""
+    import f3d
+    from f3d import synth
+    from oracle import np_ref as O
+    sc = synth.scene('C1')
+    t0 = time.perf_counter()
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.5, [86, 114, 115])
+    dtc = time.perf_counter() - t0
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    hctx = f3d.default_context(local)
+    hctx.project_vote_argmax(sc['points'][:1000], views, sc['masks'], 133, 0.5, [86, 114, 115])
+    t0 = time.perf_counter()
+    got = hctx.project_vote_argmax(sc['points'], views, sc['masks'], 133, 0.5, [86, 114, 115])
+    dtg = time.perf_counter() - t0
+    return dict(value=round(len(want) / dtc, 1), unit='points/s', cores=1, kind='port', seconds=round(dtc, 4),
+                sample='C1 in full: 100000 points x 4 views, 512x512 block-64 masks, threshold 0.5, filter [86,114,115]; oracle/np_ref.py, one process',
+                hip_host_pointer_call_s=round(dtg, 4), labels_equal=bool(np.array_equal(got, want)))
 
 
 def main():
@@ -384,6 +544,10 @@ def main():
                                points_total=total_points, points_per_gpu=n, views=V, mask_hw=[S, S], xyz_storage='f32' if args.f32 else 'f64', cloud_layout=layout,
                                chunked_step_equals_one_call=chunk_check,
                                deferred_points=dict(to_float64_tier=deferred[0], to_exact_kernel=deferred[1]),
+                               mask_alphabet=dict(labels_present=int(len(np.unique(masks_np[:8]))),
+                                                  k_fuse_instance=fuse_instance(int(len(np.unique(masks_np[:8]))), flt),
+                                                  note='block64 = the 8-label alphabet of SURVEY 8(d): the small-alphabet (dword-bin) instance, the fastest '
+                                                       'of the four; `variants` has iid / 40 / 100 labels and the filter list through the same step'),
                                exchange='none' if not use_dist else (f'RCCL all_gather of {V // world} masks/rank per step, double-buffered and overlapped with the previous step' if not chunked else
                                                                      f'RCCL all_reduce(MAX) of the label-presence bytes + {args.chunks} all_gathers of {V // world // args.chunks} masks/rank per step; chunk c+1 on the wire while chunk c votes (vote state carried in HBM)')),
                    roofline=roofline)
@@ -490,25 +654,29 @@ def main():
         del ins, cooc
         out['streaming_kernels'] = extras
 
+    if rank == 0 and world == 1 and not args.no_extras and not (args.prepared or args.sorted or overlap):
+        out['variants'] = variants_leg(torch, ctx, dev, stream, xyz, dtype, n, views, V, S, flags, perm_ptr)
+        out['c3_end_to_end'] = end_to_end_leg(torch, ctx, dev, stream, xyz, dtype, n, views, views_np, V, S, flt, flags, perm_ptr)
+
     if rank == 0 and world == 1 and not args.no_merge and not args.no_extras:
         out['merge_bb'] = merge_leg(local)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:          # reported at N=1 only
         from oracle import np_ref as O
-        cb, cls_cpu, pts_cpu, masks_cpu, (K, q, t) = cpu_baseline(args.cpu_sample, V, S, args.masks, flt)
+        cb, cls_cpu, pts_cpu, masks_cpu, (K, q, t), want0, wvotes = cpu_baseline(args.cpu_sample, V, S, args.masks, flt)
         out['cpu_baseline'] = cb
+        out['cpu_baseline_c1'] = c1_leg(local)
         # the same sample through the HIP path must give the same labels -- at the bench's threshold AND at threshold 0, where
-        # every sampled point carries a real label (at 0.5 with independent random masks ~99.9 % are 133 = "unclassified")
+        # every sampled point carries a real label (at 0.5 with independent random masks ~99.9 % are 133 = "unclassified") -- and
+        # the same vote rows; the WHOLE CPU slice at both settings
         hctx = f3d.default_context(local)
         got = hctx.project_vote_argmax(pts_cpu, views_np, masks_cpu, 133, 0.5, flt)
-        sub = min(len(pts_cpu), 1_000_000)
-        want0, wvotes = O.project_vote_argmax(pts_cpu[:sub], K, q, t, masks_cpu, 10.0, 133, 0.0, flt, return_votes=True)
-        got0, gvotes = hctx.project_vote_argmax(pts_cpu[:sub], views_np, masks_cpu, 133, 0.0, flt, return_votes=True)
-        out['parity_on_cpu_sample'] = bool(np.array_equal(got, cls_cpu) and np.array_equal(got0, want0) and
-                                           np.array_equal(gvotes.astype(np.float64), wvotes))
+        got0, gvotes = hctx.project_vote_argmax(pts_cpu, views_np, masks_cpu, 133, 0.0, flt, return_votes=True)
+        votes_equal = bool(np.array_equal(gvotes, wvotes))
+        out['parity_on_cpu_sample'] = bool(np.array_equal(got, cls_cpu) and np.array_equal(got0, want0) and votes_equal)
         out['parity_detail'] = dict(threshold_0p5=dict(points=len(pts_cpu), equal=bool(np.array_equal(got, cls_cpu)),
                                                        real_label_fraction=round(float((cls_cpu != 133).mean()), 5)),
-                                    threshold_0p0=dict(points=sub, equal=bool(np.array_equal(got0, want0)), votes_equal=bool(np.array_equal(gvotes.astype(np.float64), wvotes)),
+                                    threshold_0p0=dict(points=len(pts_cpu), equal=bool(np.array_equal(got0, want0)), votes_equal=votes_equal,
                                                        real_label_fraction=round(float((want0 != 133).mean()), 5)))
     elif rank == 0:
         out['cpu_baseline'] = None

@@ -274,6 +274,12 @@ int f3d_sem_logits_to_mask(f3d_ctx* ctx, const float* sem, int c, int64_t hw, fl
                            int low_label, uint8_t* mask);
 int f3d_sem_logits_to_mask_dev(f3d_ctx* ctx, const float* sem, int c, int64_t hw,
                                float conf_threshold, int low_label, uint8_t* mask, void* stream);
+/* The device-resident 2D -> 3D hand-off (SegmentImage's loop, get2DSeg.py:106-126, without the PNG round trip): `nimg` images of
+ * logits, float32 [nimg, c, hw], become `nimg` consecutive planes of the caller's uint8 [V, H, W] mask tensor (masks = its base
+ * + first_plane * hw) -- the tensor f3d_project_vote_argmax_dev reads.  One launch, enqueued on `stream`; no synchronisation and
+ * no copy to the host. */
+int f3d_sem_logits_to_masks_dev(f3d_ctx* ctx, const float* sem, int nimg, int c, int64_t hw,
+                                float conf_threshold, int low_label, uint8_t* masks, void* stream);
 
 /* ---- a10/a11: oriented-box membership for merge_bb (merge_intersecting_bb.py:64-91) ------- */
 /* inside_bits: uint32 [n, ceil(b/32)] -- bit k of word j of point i set iff point i lies in box

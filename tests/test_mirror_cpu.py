@@ -135,3 +135,56 @@ def test_patch_downsample_and_frame_reader_match_reference_golden(golden, tmp_pa
     assert len(fd) == 2 and name == '101' and np.array_equal(p1, g['points'][1]) and np.array_equal(ok, g['valid'][1])
     ok2 = FrameData(str(merged / 'tofsegment_demo_1.pkl'), None, 2, (h, w))[0][4]
     assert ok2.reshape(h, w)[::2, ::2].all() and ok2.sum() == (h // 2) * (w // 2)
+
+
+def test_oneformer_wrapper_calls_the_oneformer_predictor_with_task_semantic(tmp_path, monkeypatch):
+    """get2DSeg.py:12,35,77: the predictor is OneFormer's own ``demo.defaults.DefaultPredictor`` (found through the ./OneFormer
+    path entry), called as ``predictor(image, task='semantic')``; detectron2's engine predictor takes the image only.  The
+    third-party packages are absent from the image: test-local fakes on sys.path record the calls (nothing is installed)."""
+    import importlib
+    import sys
+    root = tmp_path / 'fake_site'
+    for pkg, body in {
+        'detectron2/__init__.py': '',
+        'detectron2/config.py': 'class _Cfg:\n    def __init__(self):\n        self.MODEL = type("M", (), {})()\n        self.merged = None\n'
+                                '    def merge_from_file(self, f):\n        self.merged = f\n\ndef get_cfg():\n    return _Cfg()\n',
+        'detectron2/projects/__init__.py': '',
+        'detectron2/projects/deeplab.py': 'def add_deeplab_config(cfg):\n    cfg.order = ["deeplab"]\n',
+        'detectron2/engine/__init__.py': '',
+        'detectron2/engine/defaults.py': 'class DefaultPredictor:\n    def __init__(self, cfg):\n        raise AssertionError("the reference uses '
+                                         'demo.defaults.DefaultPredictor, not detectron2\'s")\n',
+        'oneformer/__init__.py': ''.join(f'def add_{n}_config(cfg):\n    cfg.order.append("{n}")\n\n' for n in ('oneformer', 'common', 'swin', 'dinat', 'convnext')),
+        'demo/__init__.py': '',
+        'demo/defaults.py': 'calls = []\n\nclass DefaultPredictor:\n    def __init__(self, cfg):\n        self.cfg = cfg\n'
+                            '    def __call__(self, image, task):\n        calls.append((image.shape, task))\n        return {"sem_seg": "logits", "panoptic_seg": None, "instances": None}\n',
+    }.items():
+        path = root / pkg
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(body)
+    monkeypatch.syspath_prepend(str(root))
+    for name in [m for m in sys.modules if m.split('.')[0] in ('detectron2', 'oneformer', 'demo')]:
+        monkeypatch.delitem(sys.modules, name)
+    import get2DSeg
+    importlib.invalidate_caches()
+    model = get2DSeg.OneFormer()
+    out = model.predict(np.zeros((6, 8, 3), np.uint8))
+    import demo.defaults as dd
+    assert dd.calls == [((6, 8, 3), 'semantic')] and out['sem_seg'] == 'logits'
+    assert type(model.predictor) is dd.DefaultPredictor
+    assert model.predictor.cfg.order == ['deeplab', 'common', 'swin', 'dinat', 'convnext', 'oneformer']        # :46-52
+    assert model.predictor.cfg.merged.endswith('oneformer_swin_large_bs16_100ep.yaml')
+    assert model.predictor.cfg.MODEL.WEIGHTS.endswith('150_16_swin_l_oneformer_coco_100ep.pth')
+    for name in [m for m in sys.modules if m.split('.')[0] in ('detectron2', 'oneformer', 'demo')]:
+        monkeypatch.delitem(sys.modules, name)
+
+
+def test_get2dseg_seeds_like_the_reference():
+    """get2DSeg.py:83-89: every generator is seeded with 0 before the loop."""
+    import random
+    import torch
+    import get2DSeg
+    get2DSeg._seed_everything(0)
+    a = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    assert a == (random.random(), float(np.random.rand()), float(torch.rand(1)))
+    assert torch.backends.cudnn.deterministic is True and torch.backends.cudnn.benchmark is False

@@ -3,6 +3,7 @@ checked against the golden vectors / the oracle.  Needs a GPU."""
 import copy
 import json
 import pickle
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -172,6 +173,79 @@ def test_sem_to_mask_kernel(golden):
     assert clear.mean() > 0.999 and np.array_equal(got[clear], want.numpy().astype(np.uint8)[clear])
     assert (got[:4] == 133).all() and (got[4:] != 133).mean() > 0.9
     assert np.array_equal(get2DSeg.sem_to_mask(sem, 0), ts.argmax(dim=0).numpy().astype(np.uint8))    # no thresholding
+
+
+def test_device_resident_2d_to_3d_hand_off(tmp_path):
+    """Row g1 (BASELINE config 3 "end-to-end incl. the 2D backbone on PyTorch-ROCm"; get2DSeg.py:106-126): network logits on the
+    GPU -> f3d_sem_logits_to_masks_dev -> plane j of ONE uint8 [V,H,W] device tensor -> f3d_project_vote_argmax_dev, with torch's
+    sync debug mode armed ('error') over the whole hand-off: no .cpu(), no synchronisation, no PNG.  The network is the
+    stand-in with OneFormer's contract (f3d/standin.py; OneFormer is absent).  Checked: the masks against the reference's own
+    statements in torch (outside sem_mask.npz's band around the threshold), the labels against the oracle fed those masks, and
+    the PNG way out of SegmentImage against the device way."""
+    import torch
+    from PIL import Image
+    import get2DSeg
+    from f3d.standin import StandInSegNet, synthetic_frames
+    from test_oracle_golden import SEM_BAND
+    dev = torch.device('cuda', 0)
+    V, S, n = 6, 256, 40_000
+    K = np.array([[200., 0, S / 2], [0, 200., S / 2], [0, 0, 1]])
+    q, t = synth.ring_views(V)
+    pts = synth.cloud(n)
+    views = f3d.views_build(K, S, S, q, t, 10.0)
+    net = StandInSegNet().to(dev).eval()
+    frames = synthetic_frames(V, S, S, dev)
+    x, vd = torch.from_numpy(pts).to(dev), torch.from_numpy(views).to(dev)
+    masks = torch.empty((V, S, S), dtype=torch.uint8, device=dev)
+    cls = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx = f3d.default_context()
+    stream = torch.cuda.Stream(dev)
+    net(frames[:2]); torch.cuda.synchronize()                                   # GEMM selection etc. happen outside the armed region
+    batches = [frames[0:2], frames[2:4], frames[4], frames[5]]                  # batched and single-frame predictor answers
+    with torch.cuda.stream(stream):
+        torch.cuda.set_sync_debug_mode('error')
+        try:
+            out = get2DSeg.masks_to_device(batches, lambda im: {'sem_seg': net(im)}, 0.017, out=masks)
+            ctx.project_vote_argmax_dev(x.data_ptr(), f3d.F64, n, vd.data_ptr(), V, out.data_ptr(), S, S, 133, 0.0, None,
+                                        cls.data_ptr(), None, stream.cuda_stream, flags=f3d.FUSE_SORT)
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+        stream.synchronize()
+    assert out.data_ptr() == masks.data_ptr()
+    # (1) the masks: the reference's statements (:110-118) on the same logits
+    def reference_statements(sem):                                              # on [B,C,H,W]; the same GEMM shapes as the run above
+        want = sem.argmax(dim=1)
+        pmax = torch.amax(torch.nn.Softmax(dim=1)(sem), dim=1)
+        want[pmax < 0.017] = 133
+        return want.cpu().numpy().astype(np.uint8), ((pmax.double() - 0.017).abs() > SEM_BAND * 0.017).cpu().numpy()
+    parts = [reference_statements(net(b) if b.dim() == 4 else net(b)[None]) for b in batches]
+    want, clear = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    got_masks = masks.cpu().numpy()
+    assert clear.mean() > 0.999 and np.array_equal(got_masks[clear], want[clear])
+    assert 0.005 < (got_masks == 133).mean() < 0.6 and len(np.unique(got_masks)) > 10      # both branches of the threshold, many labels
+    # (2) the labels: the oracle fed the masks the device produced
+    want_cls = O.project_vote_argmax(pts, K, q, t, got_masks, 10.0, 133, 0.0, None)
+    assert np.array_equal(cls.cpu().numpy(), want_cls) and (want_cls != 133).mean() > 0.3
+    # (3) SegmentImage: the reference's PNG way and the device way give the same masks; the filter skip (:123-124) is reported, not lost
+    rgb = tmp_path / 'rgb'; rgb.mkdir()
+    host_frames = frames.cpu().numpy()
+    for j in range(V):
+        Image.fromarray(host_frames[j][:, :, ::-1]).save(rgb / f'{j:03d}.png')          # lossless, so both runs see the same pixels
+    written = get2DSeg.SegmentImage(str(rgb), str(tmp_path / 'm1'), extension='png', predictor=net.predict)
+    res = get2DSeg.SegmentImage(str(rgb), str(tmp_path / 'm2'), extension='png', predictor=net.predict, out_device=True)
+    assert [Path(w).name for w in written] == [f'{j:03d}.png' for j in range(V)] == [Path(w).name for w in res.written]
+    assert (tmp_path / 'm1' / 'viz').is_dir()
+    for j in range(V):
+        a = np.asarray(Image.open(tmp_path / 'm1' / f'{j:03d}.png'))
+        assert np.array_equal(a, res.masks[j].cpu().numpy()) and np.array_equal(a, np.asarray(Image.open(tmp_path / 'm2' / f'{j:03d}.png')))
+        w1, c1 = reference_statements(net(frames[j])[None])
+        assert np.array_equal(a[c1[0]], w1[0][c1[0]])
+    absent = sorted(set(range(133)) - set(np.unique(got_masks).tolist()))[:2]
+    res2 = get2DSeg.SegmentImage(str(rgb), str(tmp_path / 'm3'), extension='png', predictor=net.predict, filter_classes=absent, out_device=True)
+    assert res2.written == [] and not res2.kept.any().item() and res2.masks.shape == (V, S, S)
+    assert get2DSeg.SegmentImage(str(rgb), str(tmp_path / 'm4'), extension='png', predictor=net.predict, filter_classes=absent) == []
+    with pytest.raises(ValueError):
+        get2DSeg.sem_to_mask_device(net(frames[:2]), torch.empty((2, S, S + 1), dtype=torch.uint8, device=dev))
 
 
 def test_get3dseg_segment_end_to_end(tmp_path, monkeypatch):
