@@ -6,9 +6,11 @@ outer iteration is ONE kernel launch (f3d_points_in_obb*: all points x {box of i
 membership bitset in LDS, box-pair co-occurrence matrix); the control flow -- including the list-index-as-id
 and delete-while-iterating quirks (Q6/Q7) and the early return at :83-84 -- stays on the host so ids match.
 
-Oriented boxes: Open3D is optional.  With it, ``OrientedBoundingBox.create_from_points`` is used like the
-reference; without it, ``obb_from_points`` below follows the same published recipe (convex hull -> PCA of the
-hull vertices -> extents in that frame).  That fit is unpinned against Open3D.
+Oriented boxes: the fit itself (Open3D's ``OrientedBoundingBox.create_from_points``: convex hull -> PCA of the hull
+vertices -> extents in that frame) runs on the GPU for all instances of a cloud in one launch (``f3d_obb_candidates_dev`` +
+``f3d_obb_fit_dev``: hull vertex set with certified orientation signs, Jacobi eigen-solve).  An instance the kernel cannot
+certify (coplanar / duplicate points ...) is DEFERRED to the host fit ``obb_from_points`` below -- Open3D when it is installed,
+otherwise the same recipe on scipy's Qhull.  The recipe is unpinned against Open3D itself (absent from the image).
 """
 import json
 import os
@@ -166,6 +168,39 @@ class HipCloud:
             self.stream.synchronize()
             return cand.cpu().numpy()[:self.n], cnt.cpu().numpy()[:self.nids]
 
+    def candidates_and_boxes(self, min_members):
+        """All-device box fits (follows group()): hull candidates of every id in ascending point index (cand int32, cand_start int64
+        [nids + 1]), boxes float64 [nids, 15] and status int32 [nids] (f3d.OBB_OK / OBB_FEW / OBB_DEFERRED).  None without torch."""
+        if self.torch is None:
+            return None
+        torch = self.torch
+        t0 = time.perf_counter()
+        with torch.cuda.stream(self.stream):
+            cand = torch.empty(max(self.n, 1), dtype=torch.int32, device=self.device)
+            cstart = torch.empty(self.nids + 1, dtype=torch.int64, device=self.device)
+            self.ctx.obb_candidates_dev(self.dev.data_ptr(), f3d.F64, self.n, self.d_order.data_ptr(), self.d_keys.data_ptr(), self.d_starts.data_ptr(),
+                                        self.nids, min_members, cand.data_ptr(), cstart.data_ptr(), self.stream.cuda_stream)
+            self.stream.synchronize()
+            cs = cstart.cpu().numpy()
+            total = int(cs[-1])
+            self.t_candidates = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            cpts = torch.empty((max(total, 1), 3), dtype=torch.float64, device=self.device)
+            boxes = torch.empty((self.nids, f3d.OBB_DOUBLES), dtype=torch.float64, device=self.device)
+            status = torch.empty(self.nids, dtype=torch.int32, device=self.device)
+            isvert = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+            self.ctx.gather_points_dev(self.dev.data_ptr(), f3d.F64, cand.data_ptr(), total, cpts.data_ptr(), self.stream.cuda_stream)
+            self.ctx.obb_fit_dev(cpts.data_ptr(), cstart.data_ptr(), self.nids, total, boxes.data_ptr(), status.data_ptr(), isvert.data_ptr(), None,
+                                 self.stream.cuda_stream)
+            self.stream.synchronize()
+            out = cand[:total].cpu().numpy(), cs, boxes.cpu().numpy(), status.cpu().numpy()
+            self.t_fit = time.perf_counter() - t0
+            return out
+
+    def fit(self, point_sets):
+        """Boxes of a few point sets (refits after a merge): (boxes [k, 15], status [k])."""
+        return self.ctx.obb_fit(point_sets)
+
     def cooccurrence(self, packed):
         """uint8 [B, B]: some point of this process's share lies in both boxes (rows of `packed`, float64 [B, 15])."""
         B = len(packed)
@@ -207,9 +242,14 @@ class _MergeState:
 
     PREFILTER_MIN = 256                                   # instances smaller than this are fitted on all of their points
 
-    def __init__(self, pts, ids, box_fn, dist=None, backend=None):
-        self.pts, self.ids, self.box_fn, self.dist = pts, ids, box_fn, dist
-        self.prof = {'group': 0.0, 'prefilter': 0.0, 'fit': 0.0, 'nfit': 0, 'scan': 0.0, 'nscan': 0, 'absorb': 0.0, 'upload': 0.0, 'exchange': 0.0}
+    def __init__(self, pts, ids, box_fn, dist=None, backend=None, prefilter='auto'):
+        # box_fn None = the built-in fit: on the GPU, instances the kernel defers on the host (obb_from_points).  A caller-supplied
+        # box_fn gets exactly pcd_points[ids == id] unless it opts into the hull-candidate prefilter (exact for hull-based fits only).
+        self.gpu_fit = box_fn is None
+        self.pts, self.ids, self.box_fn, self.dist = pts, ids, (box_fn or obb_from_points), dist
+        self.use_prefilter = self.gpu_fit if prefilter == 'auto' else bool(prefilter)
+        self.prof = {'group': 0.0, 'prefilter': 0.0, 'fit': 0.0, 'nfit': 0, 'nfit_gpu': 0, 'nfit_deferred': 0, 'scan': 0.0, 'nscan': 0, 'absorb': 0.0,
+                     'upload': 0.0, 'exchange': 0.0}
         n = len(pts)
         self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
         share = (n * self.rank // self.world, n * (self.rank + 1) // self.world)
@@ -230,13 +270,43 @@ class _MergeState:
         self.counts = {k: len(v[0]) for k, v in self.members.items()}
         self.cands = {k: v[0] for k, v in self.members.items()}       # hull candidates: ascending point indices, a superset of the hull's vertices
         self.prof['group'] = time.perf_counter() - t0
-        if ids_ok:
+        self.boxes, self.failed = {}, {}
+        done = False
+        if ids_ok and self.gpu_fit and hasattr(self.cloud, 'candidates_and_boxes'):
+            t0 = time.perf_counter()
+            done = self._fit_all_device()
+            spent = time.perf_counter() - t0
+            self.prof['prefilter'] = getattr(self.cloud, 't_candidates', 0.0)          # extremes, inner hulls, filter, compaction: all on the device
+            self.prof['fit'] += spent - self.prof['prefilter']
+        if ids_ok and self.use_prefilter and not done:
             t0 = time.perf_counter()
             self._prefilter(starts)
             self.prof['prefilter'] = time.perf_counter() - t0
-        self.boxes, self.failed = {}, {}
-        if dist is not None:
+        if dist is not None and not done:
             self._fit_all_sharded()
+
+    def _fit_all_device(self):
+        """Candidates and boxes of every instance on the GPU (every rank of a sharded merge computes all of them: the kernels are
+        deterministic, so no exchange is needed).  Deferred instances keep their candidates and are fitted lazily on the host."""
+        res = self.cloud.candidates_and_boxes(self.PREFILTER_MIN)
+        if res is None:
+            return False
+        cand, cs, boxes, status = res
+        ok = np.flatnonzero(status == f3d.OBB_OK)
+        for k in self.members:
+            self.cands[k] = cand[cs[k]:cs[k + 1]]
+        if len(ok):
+            c, R, e = boxes[ok, 0:3], boxes[ok, 3:12].reshape(-1, 3, 3), boxes[ok, 12:15]
+            half = R * (e / 2)[:, None, :]                                          # [k, 3 (xyz), 3 (axis)]
+            signs = np.array([[-1, -1, -1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1], [1, 1, 1], [-1, 1, 1], [1, -1, 1], [1, 1, -1]], np.float64)
+            corners = c[:, None, :] + np.einsum('ja,kxa->kjx', signs, half)         # obb_corners for every box
+            pad = 1e-9 * (np.abs(corners).max(axis=(1, 2)) + np.abs(e).max(axis=1) + 1.0)
+            lo, hi = corners.min(1) - pad[:, None], corners.max(1) + pad[:, None]
+            for j, k in enumerate(ok):
+                if int(k) in self.members:
+                    self.boxes[int(k)] = (c[j].copy(), R[j].copy(), e[j].copy(), lo[j], hi[j])
+        self.prof['nfit'] += len(ok); self.prof['nfit_gpu'] += len(ok)
+        return True
 
     def _prefilter(self, starts):
         """Drop, per instance, the members strictly inside the hull of its directional extremes (exact: see HipCloud / f3d.h)."""
@@ -255,8 +325,8 @@ class _MergeState:
             p = self.pts[e]
             try:
                 eq = ConvexHull(p).equations                              # n . x + o <= 0 inside, |n| = 1
-            except QhullError:
-                continue                                                  # flat / degenerate extremes: keep every member
+            except (QhullError, ValueError):
+                continue                                                  # flat / degenerate / non-finite extremes: keep every member
             eqs.append(eq); nf[k] = len(eq)
             margin[k] = 1e-9 * (np.abs(p).max() + 1.0)
         fstart[1:] = np.cumsum(nf)
@@ -273,7 +343,16 @@ class _MergeState:
 
     def _fit(self, i):
         t0 = time.perf_counter()
-        c, R, e = self.box_fn(self.pts[self.cands[i]])
+        src = self.pts[self.cands[i]] if (self.use_prefilter or self.gpu_fit) else self.pts[np.sort(np.concatenate(self.members[i]))]
+        fitted = None
+        if self.gpu_fit and hasattr(self.cloud, 'fit') and len(src) >= 4:
+            boxes, status = self.cloud.fit([src])
+            if status[0] == f3d.OBB_OK:
+                fitted = (boxes[0, 0:3].copy(), boxes[0, 3:12].reshape(3, 3).copy(), boxes[0, 12:15].copy())
+                self.prof['nfit_gpu'] += 1
+            else:
+                self.prof['nfit_deferred'] += 1
+        c, R, e = fitted if fitted is not None else self.box_fn(src)
         corners = obb_corners(c, R, e)
         pad = 1e-9 * (np.abs(corners).max() + np.abs(e).max() + 1.0)           # the in-box test rounds; never prune a touching pair
         self.prof['fit'] += time.perf_counter() - t0; self.prof['nfit'] += 1
@@ -349,7 +428,7 @@ def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, 
 
     Same decisions as the reference, fewer scans: a partner whose box's axis-aligned bounds do not touch those of
     id1's box cannot share a point with it, so only the touching partners are tested on the GPU (exact pruning)."""
-    st = state if state is not None else _MergeState(pcd_points, id_info_per_point, box_fn or obb_from_points)
+    st = state if state is not None else _MergeState(pcd_points, id_info_per_point, box_fn)
     if st.count(id1) < 4:
         return []
     box1 = st.box(id1)
@@ -368,17 +447,18 @@ def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, 
     return [c for c, h in zip(cand, hit) if h]
 
 
-def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=None, dist=None, backend=None):
+def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=None, dist=None, backend=None, prefilter='auto'):
     """Merge same-parent instances whose boxes share a point; writes final_info.json and ids.npy (reference :103-137).
     ``dist``: an initialised ``torch.distributed`` module -- every rank calls merge_bb with the same arguments, scans its share of
     the points and gets the same result (rank 0 writes the files).  ``backend``: the object that groups and scans the cloud
-    (default: the HIP library; the CPU tests of the sharded control flow inject a NumPy one)."""
-    box_fn = box_fn or obb_from_points
+    (default: the HIP library; the CPU tests of the sharded control flow inject a NumPy one).  ``box_fn`` None = the built-in fit
+    (GPU, host for the instances the kernel defers); a caller-supplied ``box_fn`` is called on ``pcd_points[ids == id]`` like the
+    reference's, or -- ``prefilter=True``, exact for hull-based fits only -- on the instance's hull candidates."""
     n0 = len(info_sem)
     pts = np.ascontiguousarray(np.asarray(pcd.points if hasattr(pcd, 'points') else pcd), dtype=np.float64)
     t0 = time.perf_counter()
     id_list = [info_sem[i]["id"] for i in range(len(info_sem))]
-    st = _MergeState(pts, id_info_per_point, box_fn, dist, backend)
+    st = _MergeState(pts, id_info_per_point, box_fn, dist, backend, prefilter)
     for id1 in range(1, len(id_list)):
         hits = check_intersection_open3d(id1, id_list, id_info_per_point, pts, pcd, info_sem, box_fn, st)
         if hits:

@@ -1395,6 +1395,62 @@ int f3d_obb_hull_filter_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
     return F3D_OK;
 }
 
+int f3d_obb_candidates_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const int32_t* order, const uint32_t* sorted_ids,
+                           const int64_t* starts, int64_t nids, int min_members, int32_t* cand, int64_t* cand_start, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (n < 0 || n > 0x7fffffffLL || nids < 0 || nids >= 0x7fffffffLL || (nids > 0 && (!starts || !cand_start)) ||
+        (n > 0 && (!xyz || !order || !sorted_ids || !cand)))
+        return fail(ctx, F3D_ERR_INVALID, "obb_candidates: bad arguments");
+    void *table, *scratch;
+    if ((rc = ensure(ctx, SLOT_OBB_TABLE, (size_t)nids * F3D_OBB_NDIR * 8, &table))) return rc;
+    if ((rc = ensure(ctx, SLOT_OBB_FACETS, f3d_obb_candidates_scratch_bytes(n, nids), &scratch))) return rc;
+    F3D_HIP(ctx, f3d_launch_obb_candidates(xyz, dtype, n, order, sorted_ids, starts, nids, min_members, (unsigned long long*)table, scratch, cand,
+                                           cand_start, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_gather_points_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, const int32_t* idx, int64_t count, double* out, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (count < 0 || (count > 0 && (!xyz || !idx || !out))) return fail(ctx, F3D_ERR_INVALID, "gather_points: bad arguments");
+    F3D_HIP(ctx, f3d_launch_gather_points(xyz, dtype, idx, count, out, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_obb_fit_dev(f3d_ctx* ctx, const double* pts, const int64_t* start, int nfit, int64_t total, double* boxes, int32_t* status, uint8_t* isvert,
+                    int32_t* nvert, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (nfit < 0 || total < 0 || (nfit > 0 && (!start || !boxes || !status || !isvert))) return fail(ctx, F3D_ERR_INVALID, "obb_fit: bad arguments");
+    void* vlist;                                               // the vertices of every instance as a list (grows on first use only)
+    if ((rc = ensure(ctx, SLOT_OBB_CAND, (size_t)total * 4, &vlist))) return rc;
+    F3D_HIP(ctx, f3d_launch_obb_fit(pts, start, nfit, boxes, status, isvert, (int32_t*)vlist, nvert, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+int f3d_obb_fit(f3d_ctx* ctx, const double* pts, const int64_t* start, int nfit, double* boxes, int32_t* status, uint8_t* isvert, int32_t* nvert) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (nfit < 0 || (nfit > 0 && (!start || !boxes || !status))) return fail(ctx, F3D_ERR_INVALID, "obb_fit: bad arguments");
+    if (nfit == 0) return F3D_OK;
+    const int64_t total = start[nfit];
+    if (total < 0 || start[0] != 0 || (total > 0 && !pts)) return fail(ctx, F3D_ERR_INVALID, "obb_fit: start must run from 0 to the number of points");
+    for (int k = 0; k < nfit; ++k) if (start[k + 1] < start[k]) return fail(ctx, F3D_ERR_INVALID, "obb_fit: start must be non-decreasing");
+    void *dpts, *dstart, *dboxes, *dstatus, *dvert, *dnv;
+    if ((rc = ensure(ctx, SLOT_XYZ, (size_t)total * 24, &dpts)) || (rc = ensure(ctx, SLOT_AUX0, (size_t)(nfit + 1) * 8, &dstart)) ||
+        (rc = ensure(ctx, SLOT_OUT0, (size_t)nfit * sizeof(f3d_obb), &dboxes)) || (rc = ensure(ctx, SLOT_AUX1, (size_t)nfit * 8, &dstatus)) ||
+        (rc = ensure(ctx, SLOT_OUT1, (size_t)total, &dvert)))
+        return rc;
+    dnv = (char*)dstatus + (size_t)nfit * 4;
+    hipStream_t s = ctx->stream;
+    if (total) F3D_HIP(ctx, hipMemcpyAsync(dpts, pts, (size_t)total * 24, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, hipMemcpyAsync(dstart, start, (size_t)(nfit + 1) * 8, hipMemcpyHostToDevice, s));
+    if ((rc = f3d_obb_fit_dev(ctx, (const double*)dpts, (const int64_t*)dstart, nfit, total, (double*)dboxes, (int32_t*)dstatus, (uint8_t*)dvert, (int32_t*)dnv, s))) return rc;
+    F3D_HIP(ctx, hipMemcpyAsync(boxes, dboxes, (size_t)nfit * sizeof(f3d_obb), hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipMemcpyAsync(status, dstatus, (size_t)nfit * 4, hipMemcpyDeviceToHost, s));
+    if (isvert && total) F3D_HIP(ctx, hipMemcpyAsync(isvert, dvert, (size_t)total, hipMemcpyDeviceToHost, s));
+    if (nvert) F3D_HIP(ctx, hipMemcpyAsync(nvert, dnv, (size_t)nfit * 4, hipMemcpyDeviceToHost, s));
+    F3D_HIP(ctx, hipStreamSynchronize(s));
+    return F3D_OK;
+}
+
 // host-pointer sequence; the grouping (and, from the extremes call on, the cloud) stays in the context between the calls
 int f3d_group_by_id(f3d_ctx* ctx, const int64_t* ids, int64_t n, int64_t nids, int32_t* order, int64_t* starts) {
     int rc = enter(ctx); if (rc) return rc;

@@ -152,3 +152,14 @@ hipError_t f3d_launch_obb_extremes(const void* xyz, int dtype, int64_t n, const 
 hipError_t f3d_launch_obb_hull_filter(const void* xyz, int dtype, int64_t n, const int32_t* order, const uint32_t* sorted_keys,
                                       const int64_t* starts, int64_t nseg, const int32_t* fstart, const double* facets, const double* margin,
                                       int32_t* cand, int32_t* cand_count, hipStream_t s);
+// the box fit on the device (f3d_hull.hip) and the all-device candidate pipeline (f3d_obb.hip)
+#define F3D_OBB_SMALL_FACETS 48              // a triangulated hull of 26 points has at most 2 * 26 - 4 facets
+hipError_t f3d_launch_obb_fit(const double* pts, const int64_t* start, int nfit, double* boxes, int32_t* status, uint8_t* isvert, int32_t* vlist,
+                              int32_t* nvert, hipStream_t s);
+hipError_t f3d_launch_obb_small_hulls(const void* xyz, int dtype, const int32_t* extremes, const int64_t* starts, int64_t nids, int min_members,
+                                      double* gathered, uint8_t* isvert, double* facets, int32_t* nfacets, double* margin, hipStream_t s);
+size_t f3d_obb_candidates_scratch_bytes(int64_t n, int64_t nids);
+hipError_t f3d_launch_obb_candidates(const void* xyz, int dtype, int64_t n, const int32_t* order, const uint32_t* sorted_keys, const int64_t* starts,
+                                     int64_t nids, int min_members, unsigned long long* table, void* scratch, int32_t* cand, int64_t* cand_start,
+                                     hipStream_t s);
+hipError_t f3d_launch_gather_points(const void* xyz, int dtype, const int32_t* idx, int64_t count, double* out, hipStream_t s);

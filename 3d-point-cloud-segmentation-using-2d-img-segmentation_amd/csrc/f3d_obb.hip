@@ -53,7 +53,6 @@ __device__ __forceinline__ uint32_t fbits(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-#define F3D_OBB_NDIR 26
 // the 13 axes; direction 2k = +axis k, 2k + 1 = -axis k
 __device__ __forceinline__ void dir_dots(float x, float y, float z, float d[13]) {
     d[0] = x; d[1] = y; d[2] = z;
@@ -143,6 +142,113 @@ __global__ __launch_bounds__(OB) void k_obb_hull_filter(const T* __restrict__ xy
     }
 }
 
+// ---- the all-device candidate pipeline: survivors of the inner-hull test as a bit per position of `order`, then a stable compaction
+// (ascending point index inside every instance: the order the reference's pcd_points[ids == id] has)
+// facets: [nseg][F3D_OBB_SMALL_FACETS][4] with nfacets[seg] of them in use (0: the instance keeps every member)
+template <typename T>
+__global__ __launch_bounds__(OB) void k_obb_filter_mask(const T* __restrict__ xyz, int64_t n, const int32_t* __restrict__ order,
+                                                         const uint32_t* __restrict__ keys, int64_t nseg, const int32_t* __restrict__ nfacets,
+                                                         const double* __restrict__ facets, const double* __restrict__ margin,
+                                                         unsigned long long* __restrict__ maskw) {
+    const int64_t nwork = (n + 63) & ~(int64_t)63;
+    for (int64_t i = (int64_t)blockIdx.x * OB + threadIdx.x; i < nwork; i += (int64_t)gridDim.x * OB) {
+        bool keep = false;
+        if (i < n) {
+            const uint32_t seg = keys[i];
+            if (seg < (uint32_t)nseg) {
+                const int nf = nfacets[seg];
+                bool inside = nf > 0;
+                if (inside) {
+                    double x, y, z;
+                    load3(xyz, (int64_t)order[i], x, y, z);
+                    const double mg = -margin[seg];
+                    const double* e = facets + (size_t)seg * F3D_OBB_SMALL_FACETS * 4;
+                    for (int f = 0; f < nf && inside; ++f, e += 4)
+                        inside = (__builtin_fma(e[0], x, __builtin_fma(e[1], y, __builtin_fma(e[2], z, e[3]))) < mg);
+                }
+                keep = !inside;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if ((threadIdx.x & 63) == 0) maskw[i >> 6] = m;
+    }
+}
+
+constexpr int SCAN_WORDS = 4096;             // mask words per block of the prefix pass (256 threads x 16)
+// wordoff[w] = survivors in the words before w INSIDE its block of SCAN_WORDS words; blocksum[b] = the block's total
+__global__ __launch_bounds__(OB) void k_mask_scan_local(const unsigned long long* __restrict__ maskw, int64_t nwords, uint32_t* __restrict__ wordoff,
+                                                         uint32_t* __restrict__ blocksum) {
+    __shared__ uint32_t part[OB];
+    const int64_t w0 = (int64_t)blockIdx.x * SCAN_WORDS + (int64_t)threadIdx.x * 16;
+    uint32_t c[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { c[k] = (w0 + k < nwords) ? (uint32_t)__popcll(maskw[w0 + k]) : 0u; sum += c[k]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < OB; off <<= 1) {
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { if (w0 + k < nwords) wordoff[w0 + k] = run; run += c[k]; }
+    if (threadIdx.x == OB - 1) blocksum[blockIdx.x] = part[OB - 1];
+}
+
+// one block: blocksum -> exclusive prefix in place; total[0] = the number of survivors
+__global__ __launch_bounds__(OB) void k_mask_scan_blocks(uint32_t* __restrict__ blocksum, int nblocks, int64_t* __restrict__ total) {
+    __shared__ uint32_t part[OB];
+    const int per = (nblocks + OB - 1) / OB;
+    const int lo = threadIdx.x * per, hi = min(nblocks, lo + per);
+    uint32_t sum = 0;
+    for (int k = lo; k < hi; ++k) sum += blocksum[k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < OB; off <<= 1) {
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int k = lo; k < hi; ++k) { const uint32_t c = blocksum[k]; blocksum[k] = run; run += c; }
+    if (threadIdx.x == OB - 1) *total = (int64_t)part[OB - 1];
+}
+
+__device__ __forceinline__ int64_t survivors_before(int64_t pos, int64_t n, const unsigned long long* __restrict__ maskw, const uint32_t* __restrict__ wordoff,
+                                                    const uint32_t* __restrict__ blockoff, int64_t total) {
+    if (pos >= n) return total;
+    const int64_t w = pos >> 6;
+    return (int64_t)blockoff[w / SCAN_WORDS] + wordoff[w] + __popcll(maskw[w] & ((1ull << (pos & 63)) - 1ull));
+}
+
+__global__ __launch_bounds__(OB) void k_obb_compact(int64_t n, const int32_t* __restrict__ order, const unsigned long long* __restrict__ maskw,
+                                                     const uint32_t* __restrict__ wordoff, const uint32_t* __restrict__ blockoff, int32_t* __restrict__ cand) {
+    for (int64_t i = (int64_t)blockIdx.x * OB + threadIdx.x; i < n; i += (int64_t)gridDim.x * OB) {
+        const int64_t w = i >> 6;
+        const unsigned long long m = maskw[w];
+        if ((m >> (i & 63)) & 1ull) cand[(int64_t)blockoff[w / SCAN_WORDS] + wordoff[w] + __popcll(m & ((1ull << (i & 63)) - 1ull))] = order[i];
+    }
+}
+
+__global__ __launch_bounds__(OB) void k_obb_cand_starts(int64_t n, const int64_t* __restrict__ starts, int64_t nseg, const unsigned long long* __restrict__ maskw,
+                                                         const uint32_t* __restrict__ wordoff, const uint32_t* __restrict__ blockoff,
+                                                         const int64_t* __restrict__ total, int64_t* __restrict__ cand_start) {
+    const int64_t k = (int64_t)blockIdx.x * OB + threadIdx.x;
+    if (k > nseg) return;
+    cand_start[k] = survivors_before(starts[k], n, maskw, wordoff, blockoff, *total);     // starts[nseg] = first position of the out-of-range bucket
+}
+
+template <typename T>
+__global__ __launch_bounds__(OB) void k_gather_points(const T* __restrict__ xyz, const int32_t* __restrict__ idx, int64_t count, double* __restrict__ out) {
+    for (int64_t j = (int64_t)blockIdx.x * OB + threadIdx.x; j < count; j += (int64_t)gridDim.x * OB) {
+        const int64_t i = idx[j];
+        out[3 * j] = (double)xyz[3 * i]; out[3 * j + 1] = (double)xyz[3 * i + 1]; out[3 * j + 2] = (double)xyz[3 * i + 2];
+    }
+}
+
 inline int grid_for(int64_t n, int cap) {
     int64_t g = (n + OB - 1) / OB;
     if (g < 1) g = 1;
@@ -223,5 +329,69 @@ hipError_t f3d_launch_obb_hull_filter(const void* xyz, int dtype, int64_t n, con
         hipLaunchKernelGGL(k_obb_hull_filter<double>, g, b, 0, s, (const double*)xyz, n, order, sorted_keys, starts, nseg, fstart, facets, margin, cand, cand_count);
     else
         hipLaunchKernelGGL(k_obb_hull_filter<float>, g, b, 0, s, (const float*)xyz, n, order, sorted_keys, starts, nseg, fstart, facets, margin, cand, cand_count);
+    return hipGetLastError();
+}
+
+// ---- candidates of every instance without a host round trip -----------------------------------------------------------------------
+namespace {
+struct cand_layout { size_t extremes, gathered, isvert, facets, nfacets, margin, maskw, wordoff, blocksum, total, bytes; int64_t nwords; int nblocks; };
+cand_layout cand_layout_for(int64_t n, int64_t nids) {
+    cand_layout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    L.nwords = (n + 63) / 64;
+    L.nblocks = (int)((L.nwords + SCAN_WORDS - 1) / SCAN_WORDS);
+    L.extremes = take((size_t)nids * F3D_OBB_NDIR * 4);
+    L.gathered = take((size_t)nids * F3D_OBB_NDIR * 24);
+    L.isvert = take((size_t)nids * F3D_OBB_NDIR);
+    L.facets = take((size_t)nids * F3D_OBB_SMALL_FACETS * 32);
+    L.nfacets = take((size_t)nids * 4);
+    L.margin = take((size_t)nids * 8);
+    L.maskw = take((size_t)L.nwords * 8);
+    L.wordoff = take((size_t)L.nwords * 4);
+    L.blocksum = take((size_t)(L.nblocks + 1) * 4);
+    L.total = take(8);
+    L.bytes = off;
+    return L;
+}
+}  // namespace
+
+size_t f3d_obb_candidates_scratch_bytes(int64_t n, int64_t nids) { return cand_layout_for(n < 1 ? 1 : n, nids < 1 ? 1 : nids).bytes; }
+
+hipError_t f3d_launch_obb_candidates(const void* xyz, int dtype, int64_t n, const int32_t* order, const uint32_t* sorted_keys, const int64_t* starts,
+                                     int64_t nids, int min_members, unsigned long long* table, void* scratch, int32_t* cand, int64_t* cand_start,
+                                     hipStream_t s) {
+    if (nids <= 0) return hipSuccess;
+    if (n <= 0) return hipMemsetAsync(cand_start, 0, (size_t)(nids + 1) * 8, s);
+    const cand_layout L = cand_layout_for(n, nids);
+    char* base = reinterpret_cast<char*>(scratch);
+    int32_t* extremes = reinterpret_cast<int32_t*>(base + L.extremes);
+    double* gathered = reinterpret_cast<double*>(base + L.gathered);
+    uint8_t* isvert = reinterpret_cast<uint8_t*>(base + L.isvert);
+    double* facets = reinterpret_cast<double*>(base + L.facets);
+    int32_t* nfacets = reinterpret_cast<int32_t*>(base + L.nfacets);
+    double* margin = reinterpret_cast<double*>(base + L.margin);
+    unsigned long long* maskw = reinterpret_cast<unsigned long long*>(base + L.maskw);
+    uint32_t* wordoff = reinterpret_cast<uint32_t*>(base + L.wordoff);
+    uint32_t* blocksum = reinterpret_cast<uint32_t*>(base + L.blocksum);
+    int64_t* total = reinterpret_cast<int64_t*>(base + L.total);
+    hipError_t e = f3d_launch_obb_extremes(xyz, dtype, n, order, sorted_keys, nids, table, extremes, s);
+    if (e != hipSuccess) return e;
+    if ((e = f3d_launch_obb_small_hulls(xyz, dtype, extremes, starts, nids, min_members, gathered, isvert, facets, nfacets, margin, s)) != hipSuccess) return e;
+    const dim3 g(grid_for(n, 8192)), b(OB);
+    if (dtype == F3D_F64) hipLaunchKernelGGL(k_obb_filter_mask<double>, g, b, 0, s, (const double*)xyz, n, order, sorted_keys, nids, nfacets, facets, margin, maskw);
+    else hipLaunchKernelGGL(k_obb_filter_mask<float>, g, b, 0, s, (const float*)xyz, n, order, sorted_keys, nids, nfacets, facets, margin, maskw);
+    hipLaunchKernelGGL(k_mask_scan_local, dim3(L.nblocks), b, 0, s, maskw, L.nwords, wordoff, blocksum);
+    hipLaunchKernelGGL(k_mask_scan_blocks, dim3(1), b, 0, s, blocksum, L.nblocks, total);
+    hipLaunchKernelGGL(k_obb_compact, g, b, 0, s, n, order, maskw, wordoff, blocksum, cand);
+    hipLaunchKernelGGL(k_obb_cand_starts, dim3(grid_for(nids + 1, 65536)), b, 0, s, n, starts, nids, maskw, wordoff, blocksum, total, cand_start);
+    return hipGetLastError();
+}
+
+hipError_t f3d_launch_gather_points(const void* xyz, int dtype, const int32_t* idx, int64_t count, double* out, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    const dim3 g(grid_for(count, 8192)), b(OB);
+    if (dtype == F3D_F64) hipLaunchKernelGGL(k_gather_points<double>, g, b, 0, s, (const double*)xyz, idx, count, out);
+    else hipLaunchKernelGGL(k_gather_points<float>, g, b, 0, s, (const float*)xyz, idx, count, out);
     return hipGetLastError();
 }

@@ -24,6 +24,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_INDEX, ERR_ZERO_QUAT, ERR_NOMEM = 0, -1, -2, -3, -
 VIEW_DOUBLES = 88            # sizeof(f3d_view) / 8
 OBB_DOUBLES = 15             # sizeof(f3d_obb) / 8
 MAX_OBB = 4096
+OBB_OK, OBB_FEW, OBB_DEFERRED = 0, 1, 2
 
 
 class F3DError(RuntimeError):
@@ -107,6 +108,10 @@ def library():
         'f3d_group_by_id_dev': (i32, [vp, vp, i64, i64, vp, vp, vp, vp]),
         'f3d_obb_extremes_dev': (i32, [vp, vp, i32, i64, vp, vp, i64, vp, vp]),
         'f3d_obb_hull_filter_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
+        'f3d_obb_fit': (i32, [vp, vp, vp, i32, vp, vp, vp, vp]),
+        'f3d_obb_fit_dev': (i32, [vp, vp, vp, i32, i64, vp, vp, vp, vp, vp]),
+        'f3d_obb_candidates_dev': (i32, [vp, vp, i32, i64, vp, vp, vp, i64, i32, vp, vp, vp]),
+        'f3d_gather_points_dev': (i32, [vp, vp, i32, vp, i64, vp, vp]),
         'f3d_relabel': (i32, [vp, vp, i64, i64, i64, vp]),
         'f3d_relabel_dev': (i32, [vp, vp, i64, i64, i64, vp, vp]),
         'f3d_ray_x_lines': (i32, [vp, vp, vp, vp, vp, i64, vp, vp]),
@@ -416,6 +421,22 @@ class Context:
         self._check(self._lib.f3d_obb_hull_filter(self._h, n, _ptr(fs), _ptr(eq), _ptr(mg), _ptr(cand), _ptr(cnt)))
         return cand, cnt
 
+    def obb_fit(self, point_sets, want_vertices=False):
+        """Oriented boxes (Open3D's create_from_points recipe) of a list of point sets in ONE launch: boxes float64 [k, 15] (center,
+        R row-major with the axes as columns, extent), status int32 [k] (OBB_OK / OBB_FEW / OBB_DEFERRED: fit that one on the host);
+        with want_vertices also a list of bool arrays marking every set's hull vertices."""
+        sets = [_f64(np.asarray(p).reshape(-1, 3)) for p in point_sets]
+        start = np.zeros(len(sets) + 1, np.int64)
+        start[1:] = np.cumsum([len(p) for p in sets])
+        pts = np.ascontiguousarray(np.concatenate(sets)) if sets and start[-1] else np.zeros((0, 3))
+        boxes = np.zeros((len(sets), OBB_DOUBLES))
+        status = np.zeros(len(sets), np.int32)
+        isvert = np.zeros(len(pts), np.uint8) if want_vertices else None
+        self._check(self._lib.f3d_obb_fit(self._h, _ptr(pts), _ptr(start), len(sets), _ptr(boxes), _ptr(status), _ptr(isvert), None))
+        if want_vertices:
+            return boxes, status, [isvert[start[k]:start[k + 1]].view(np.bool_) for k in range(len(sets))]
+        return boxes, status
+
     def relabel(self, ids, from_id, to_id):
         if ids.dtype != np.int64 or not ids.flags.c_contiguous:
             raise ValueError('ids must be a C-contiguous int64 array')
@@ -644,6 +665,16 @@ class Context:
                             cand_ptr, cand_count_ptr, stream=None):
         self._check(self._lib.f3d_obb_hull_filter_dev(self._h, xyz_ptr, dtype, n, order_ptr, sorted_ids_ptr, starts_ptr, int(nids), fstart_ptr,
                                                       facets_ptr, margin_ptr, cand_ptr, cand_count_ptr, stream))
+
+    def obb_candidates_dev(self, xyz_ptr, dtype, n, order_ptr, sorted_ids_ptr, starts_ptr, nids, min_members, cand_ptr, cand_start_ptr, stream=None):
+        self._check(self._lib.f3d_obb_candidates_dev(self._h, xyz_ptr, dtype, n, order_ptr, sorted_ids_ptr, starts_ptr, int(nids), int(min_members),
+                                                     cand_ptr, cand_start_ptr, stream))
+
+    def gather_points_dev(self, xyz_ptr, dtype, idx_ptr, count, out_ptr, stream=None):
+        self._check(self._lib.f3d_gather_points_dev(self._h, xyz_ptr, dtype, idx_ptr, int(count), out_ptr, stream))
+
+    def obb_fit_dev(self, pts_ptr, start_ptr, nfit, total, boxes_ptr, status_ptr, isvert_ptr, nvert_ptr=None, stream=None):
+        self._check(self._lib.f3d_obb_fit_dev(self._h, pts_ptr, start_ptr, int(nfit), int(total), boxes_ptr, status_ptr, isvert_ptr, nvert_ptr, stream))
 
     def relabel_dev(self, ids_ptr, n, from_id, to_id, count_ptr=None, stream=None):
         self._check(self._lib.f3d_relabel_dev(self._h, ids_ptr, n, int(from_id), int(to_id), count_ptr, stream))

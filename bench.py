@@ -156,14 +156,16 @@ def merge_leg(local):
     o_info, o_ids = O.merge_bb(copy.deepcopy(f2), i2.copy(), p2)
     dtc = time.perf_counter() - t0
     with contextlib.redirect_stdout(sys.stderr):
-        g_info, g_ids = M.merge_bb(None, copy.deepcopy(f2), i2.copy(), p2, box_fn=O.obb_from_points)
+        g_info, g_ids = M.merge_bb(None, copy.deepcopy(f2), i2.copy(), p2)                  # the product's own (GPU) fit against the oracle's
     same = bool(np.array_equal(g_ids, o_ids) and [(d['id'], d['area']) for d in g_info] == [(d['id'], d['area']) for d in o_info])
     return dict(workload=f'C5 merge: {n} points, {B} instances (Gaussian blobs, parent = id mod 8) -> {len(out_info)} entries',
                 seconds=round(dt, 3), points_per_s=round(n / dt, 1),
                 breakdown_s={k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()},
                 algorithmic_bytes_per_scan=24 * n,
-                note='host-pointer call: the 1.2 GB cloud is uploaded inside the timed region (breakdown_s.upload); box fits = host Qhull on the '
-                     'survivors of the GPU inner-hull filter; scans = k_points_in_obb launches',
+                note='host-pointer call: the 1.2 GB cloud is uploaded inside the timed region (breakdown_s.upload); prefilter = extremes, inner hulls, '
+                     'strict-inside filter and ordered compaction, all on the device (f3d_obb_candidates_dev); fit = f3d_obb_fit_dev for every instance in one '
+                     'launch (hull vertices with certified signs, PCA, Jacobi) + refits after merges (nfit_deferred = fits the kernel handed to the host); '
+                     'scans = k_points_in_obb launches',
                 cpu_baseline=dict(value=round(dtc, 2), unit='s', cores=1, kind='port',
                                   sample=f'oracle/np_ref.py::merge_bb (reference control flow, O(B^2) refits and scans) on {ns} points, {Bs} '
                                          f'instances of the same recipe; its cost grows like B^2 N / 8, i.e. ~{dtc * (B / Bs) ** 2 * (n / ns) / 3600:.0f} h '

@@ -321,6 +321,37 @@ int f3d_obb_hull_filter_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int6
                             const uint32_t* sorted_ids, const int64_t* starts, int64_t nids, const int32_t* facet_start,
                             const double* facets, const double* margin, int32_t* cand, int32_t* cand_count, void* stream);
 
+/* ---- a11: the oriented-box fit itself (Open3D's OrientedBoundingBox.create_from_points at merge_intersecting_bb.py:75,86,126 and
+ * get3DSeg.py:434-435): convex hull -> mean / covariance of the hull vertices -> eigenvectors by descending eigenvalue, third axis =
+ * first x second -> extents of the hull vertices in that frame.  One wavefront per instance: hull vertex set by gift wrapping with
+ * CERTIFIED orientation signs (float64 + static error bound), cyclic Jacobi for the 3 x 3 eigen-problem.
+ * pts: float64 [total, 3], the instances' points back to back (a superset of each hull's vertices is enough: f3d_obb_candidates_dev);
+ * start int64 [nfit + 1]: instance k owns pts[start[k] .. start[k + 1]).  boxes: f3d_obb [nfit] (center, R row-major with the axes
+ * as columns, extent).  status int32 [nfit]: F3D_OBB_OK; F3D_OBB_FEW = fewer than 4 points; F3D_OBB_DEFERRED = a sign could not be
+ * certified (coplanar / duplicate points, non-finite coordinates, a facet with more than 3 vertices) or the frontier outgrew its
+ * LDS table -- nothing is guessed, the caller fits that instance on the host (Qhull raises for the truly flat ones, like Open3D).
+ * isvert (optional) uint8 [total]: 1 for the hull vertices.  nvert (optional) int32 [nfit].
+ * Axis signs: the largest component of the first two axes is positive (the box as a point set does not depend on them; LAPACK /
+ * Eigen do not specify theirs).  Open3D itself is absent from the build image: parity with it is unpinned. */
+#define F3D_OBB_OK 0
+#define F3D_OBB_FEW 1
+#define F3D_OBB_DEFERRED 2
+int f3d_obb_fit(f3d_ctx* ctx, const double* pts, const int64_t* start, int nfit, double* boxes, int32_t* status,
+                uint8_t* isvert, int32_t* nvert);
+int f3d_obb_fit_dev(f3d_ctx* ctx, const double* pts, const int64_t* start, int nfit, int64_t total /* = start[nfit] */,
+                    double* boxes, int32_t* status, uint8_t* isvert /*device, required*/, int32_t* nvert, void* stream);
+/* Hull candidates of EVERY instance in device passes (follows f3d_group_by_id_dev of the same cloud): directional extremes ->
+ * hulls of the <= 26 extremes on the device (the same certified wave code) -> members strictly inside that inner polytope are
+ * dropped -> the survivors compacted in ascending point index.  cand int32 [n] (capacity): the candidates of id 0, id 1, ... back to
+ * back; cand_start int64 [nids + 1].  Instances with fewer than min_members members, or whose inner hull cannot be certified, keep
+ * every member.  The hull -- hence the box -- of an instance's candidates is that of all of its members. */
+int f3d_obb_candidates_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const int32_t* order,
+                           const uint32_t* sorted_ids, const int64_t* starts, int64_t nids, int min_members,
+                           int32_t* cand, int64_t* cand_start, void* stream);
+/* out[j] = (double) xyz[idx[j]], j < count: the compact point array f3d_obb_fit_dev reads */
+int f3d_gather_points_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, const int32_t* idx, int64_t count, double* out,
+                          void* stream);
+
 /* ---- a12 / (f)#4: the other primitives of Fusion3DSeg/intersections.py (host pointers) ---- */
 /* ray_x_lines (:6-38): points [n,3], within uint8 [n] */
 int f3d_ray_x_lines(f3d_ctx* ctx, const double origin[3], const double direction[3], const double* starts,

@@ -128,7 +128,10 @@ def test_points_in_obb_and_relabel_kernels():
     assert ctx.relabel(moved, 999, 0) == 0
 
 
-def test_merge_bb_matches_oracle_control_flow(tmp_path):
+def test_merge_bb_control_flow_with_the_oracles_fit_injected(tmp_path):
+    """Control flow, quirks (Q6/Q7), scans and files -- with a GIVEN fit: the oracle's obb_from_points is injected as box_fn (called
+    on pcd_points[ids == id] like the reference's), so this test says nothing about the product's own fit (see
+    test_merge_bb_own_gpu_fit_end_to_end_against_the_oracle)."""
     from Fusion3DSeg.merge_intersecting_bb import merge_bb
     rng = np.random.default_rng(9)
     pts, ids = _blobs(rng, 14, 250, spread=3.0)
@@ -298,7 +301,8 @@ def test_get3dseg_segment_end_to_end(tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize('seed,nblobs,spread', [(31, 40, 4.0), (32, 60, 9.0)])
-def test_merge_bb_randomised_against_oracle(seed, nblobs, spread):
+def test_merge_bb_randomised_control_flow_with_the_oracles_fit_injected(seed, nblobs, spread):
+    """Control flow with a given fit (the oracle's, injected), random scenes incl. instances with fewer than 4 points (:83-84)."""
     from Fusion3DSeg.merge_intersecting_bb import merge_bb
     rng = np.random.default_rng(seed)
     pts, ids = _blobs(rng, nblobs, 120, spread=spread)
@@ -380,41 +384,184 @@ def test_group_by_id_extremes_and_hull_filter_kernels():
     assert dropped > 0.8 * (ids >= 0).sum() * 0.7                      # the filter really removes most members
 
 
-def test_merge_bb_c5_recipe_against_oracle_and_prefilter_off():
-    """merge_bb on the C5 recipe (Gaussian blobs, parent = id mod 8): equal to the oracle's literal control flow at a size the
-    oracle can afford, and -- 2M points, 512 instances -- equal with the hull prefilter switched off (boxes bit for bit)."""
+def _same_boxes(got_info, want_info, tol=1e-8):
+    """'bbox' entries as corner SETS (the eigenvector signs, hence the corner order, are a convention: f3d.h)."""
+    for g, w in zip(got_info, want_info):
+        assert ('bbox' in g) == ('bbox' in w), (g.get('id'), w.get('id'))
+        if 'bbox' in g:
+            a, b = np.array(g['bbox']), np.array(w['bbox'])
+            d = np.abs(a[:, None, :] - b[None, :, :]).max(-1)
+            assert (d.min(1) < tol).all() and (d.min(0) < tol).all(), (g['id'], d.min(1).max())
+
+
+def test_merge_bb_own_gpu_fit_end_to_end_against_the_oracle():
+    """The product's OWN fit (f3d_obb_candidates_dev + f3d_obb_fit_dev, no box_fn) end to end against the oracle's literal restatement
+    of merge_bb with its scipy / LAPACK fit: same ids, areas and entries; boxes equal as corner sets within 1e-8 (the hull vertex
+    sets are identical, the eigen-solvers differ in the last bits; Open3D itself is absent: parity with it unpinned)."""
+    import Fusion3DSeg.merge_intersecting_bb as M
+    for B, n, seed in [(160, 40_000, 3456), (96, 150_000, 99)]:
+        pts, ids, info = _c5_blobs(B, n, seed)
+        want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
+        prof = {}
+        keep = M._MergeState.__init__
+
+        def spy(self, *a, **k):
+            keep(self, *a, **k)
+            prof['st'] = self
+        M._MergeState.__init__ = spy
+        try:
+            got_info, got_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts)
+        finally:
+            M._MergeState.__init__ = keep
+        assert np.array_equal(got_ids, want_ids) and len(got_info) < len(info)
+        assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info]
+        _same_boxes(got_info, want_info)
+        st = prof['st'].prof
+        assert st['nfit_gpu'] >= B - 2 and st['nfit_deferred'] == 0, st          # the fits really ran on the GPU
+
+
+def test_merge_bb_c5_recipe_with_the_oracles_fit_and_prefilter_off():
+    """merge_bb on the C5 recipe (Gaussian blobs, parent = id mod 8): control flow with the oracle's fit injected (on all members and
+    on the hull candidates: the same boxes bit for bit), and -- 2M points, 512 instances, the product's own GPU fit -- the same
+    result with the hull prefilter switched off (the vertex set, hence the box, does not depend on which candidates came along)."""
     import Fusion3DSeg.merge_intersecting_bb as M
     pts, ids, info = _c5_blobs(160, 40_000)
     want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
-    got_info, got_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts, box_fn=O.obb_from_points)
-    assert np.array_equal(got_ids, want_ids) and len(got_info) < len(info)
-    assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info]
-    for g, w in zip(got_info, want_info):
-        assert ('bbox' in g) == ('bbox' in w) and ('bbox' not in g or np.array_equal(np.array(g['bbox']), np.array(w['bbox'])))
+    for pf in (False, True):
+        got_info, got_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts, box_fn=O.obb_from_points, prefilter=pf)
+        assert np.array_equal(got_ids, want_ids) and len(got_info) < len(info)
+        assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info]
+        for g, w in zip(got_info, want_info):
+            assert ('bbox' in g) == ('bbox' in w) and ('bbox' not in g or np.array_equal(np.array(g['bbox']), np.array(w['bbox'])))
     pts, ids, info = _c5_blobs(512, 2_000_000)
     a_info, a_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts)
     keep = M._MergeState.PREFILTER_MIN
     try:
-        M._MergeState.PREFILTER_MIN = 1 << 60
+        M._MergeState.PREFILTER_MIN = 1 << 30
         b_info, b_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts)
     finally:
         M._MergeState.PREFILTER_MIN = keep
     assert np.array_equal(a_ids, b_ids) and json.dumps(a_info) == json.dumps(b_info) and len(a_info) < len(info)
 
 
+def test_obb_fit_kernel_hull_vertices_and_boxes():
+    """f3d_obb_fit: the hull vertex set equals scipy's Qhull (ConvexHull(...).vertices) on every set the kernel certifies; the box
+    equals the oracle's recipe (hull -> PCA -> extents; LAPACK eigh) up to the axis signs: centre / extent within 1e-9 relative,
+    axes within 1e-7 (|cos| of the angle; eigenvectors of close eigenvalues are ill-conditioned), corners as sets.  Sets it must
+    not certify (fewer than 4 points, coplanar, duplicates, NaN) come back FEW / DEFERRED -- never a guessed box."""
+    from scipy.spatial import ConvexHull
+    ctx = f3d.default_context()
+    rng = np.random.default_rng(12)
+    sets = []
+    for k in range(400):
+        m = int(rng.choice([4, 5, 6, 9, 26, 60, 150, 700, 3000]))
+        kind = k % 4
+        if kind == 0:
+            p = rng.normal(size=(m, 3)) * rng.uniform(0.05, 2.0, 3)
+        elif kind == 1:
+            p = rng.uniform(-1, 1, (m, 3)) * rng.uniform(0.1, 3.0, 3)
+        elif kind == 2:                                              # points ON a sphere: every point is a vertex
+            p = rng.normal(size=(m, 3)); p /= np.linalg.norm(p, axis=1)[:, None]
+        else:                                                        # float32-representable coordinates far from the origin
+            p = (rng.normal(size=(m, 3)) * 0.15 + rng.uniform(-50, 50, 3)).astype(np.float32).astype(np.float64)
+        q = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        sets.append(p @ q.T + rng.uniform(-5, 5, 3))
+    boxes, status, verts = ctx.obb_fit(sets, want_vertices=True)
+    ok = 0
+    for k, p in enumerate(sets):
+        if status[k] != f3d.OBB_OK:
+            # the only deferrals of this seeded run: 3000 points ON a sphere -- a hull of 3000 vertices / 5996 facets, whose frontier
+            # outgrows the 1024-edge LDS table (a capacity deferral, not a guess: the host fits those)
+            assert status[k] == f3d.OBB_DEFERRED and k % 4 == 2 and len(p) == 3000, k
+            continue
+        ok += 1
+        assert np.array_equal(np.flatnonzero(verts[k]), np.sort(ConvexHull(p).vertices)), k
+        c, R, e = O.obb_from_points(p)
+        gc, gR, ge = boxes[k, 0:3], boxes[k, 3:12].reshape(3, 3), boxes[k, 12:15]
+        scale = np.abs(p).max()
+        gap = np.diff(np.sort(np.linalg.eigvalsh(np.cov((p[verts[k]] - p[verts[k]].mean(0)).T, bias=True)))).min() / scale ** 2
+        tol = 1e-9 * scale / max(gap, 1e-6)
+        assert np.allclose(np.abs(np.sum(gR * R, axis=0)), 1.0, atol=1e-7 / max(gap, 1e-6)), (k, gap)
+        assert np.abs(gc - c).max() < tol and np.abs(ge - e).max() < tol, (k, gap)
+        assert abs(np.linalg.det(gR) - 1.0) < 1e-12 and np.allclose(gR.T @ gR, np.eye(3), atol=1e-12)
+        assert (gR[np.abs(gR[:, 0]).argmax(), 0] > 0) and (gR[np.abs(gR[:, 1]).argmax(), 1] > 0)      # the sign convention of f3d.h
+    assert ok >= 390                                                 # random data is in general position: everything else is certified
+    # what must not be certified
+    flat = rng.normal(size=(50, 3)); flat[:, 2] = 0.25
+    dup = rng.normal(size=(40, 3)); dup[7] = dup[3]
+    cube = np.array([[x, y, z] for x in (0., 1) for y in (0., 1) for z in (0., 1)])      # four coplanar points per face
+    nan = rng.normal(size=(30, 3)); nan[4, 1] = np.nan
+    b2, s2 = ctx.obb_fit([flat, rng.normal(size=(3, 3)), np.zeros((0, 3)), dup, cube, nan, flat @ np.linalg.qr(rng.normal(size=(3, 3)))[0]])
+    assert s2.tolist() == [f3d.OBB_DEFERRED, f3d.OBB_FEW, f3d.OBB_FEW, f3d.OBB_DEFERRED, f3d.OBB_DEFERRED, f3d.OBB_DEFERRED, f3d.OBB_DEFERRED]
+    assert (b2 == 0).all()
+    # the same bits in every run, and a box does not depend on which non-vertices came along
+    again, _ = ctx.obb_fit(sets[:50])
+    assert np.array_equal(again, boxes[:50])
+    k = next(i for i, p in enumerate(sets) if status[i] == f3d.OBB_OK and len(p) >= 700)
+    only_vertices, st1 = ctx.obb_fit([sets[k][verts[k]]])
+    assert st1[0] == f3d.OBB_OK and np.array_equal(only_vertices[0], boxes[k])
+
+
+def test_obb_candidates_pipeline_on_the_device():
+    """f3d_obb_candidates_dev: per id a subset of its members in ascending point index that contains every vertex of the hull of all
+    members (so the box of the candidates is the box of the instance); small instances and uncertifiable inner hulls keep every
+    member; ids outside [0, nids) are ignored."""
+    import torch
+    from scipy.spatial import ConvexHull
+    ctx = f3d.default_context()
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(23)
+    nids, n = 41, 90_000
+    ids = rng.integers(-2, nids + 3, n).astype(np.int64)
+    ids[ids == 5] = 6                                                  # an id without members
+    small = np.flatnonzero(ids == 9); ids[small[100:]] = 10            # an id below min_members
+    centres = rng.uniform(-4, 4, (nids + 3, 3))
+    pts = centres[np.clip(ids, 0, nids + 2)] + rng.normal(size=(n, 3)) * [0.4, 0.2, 0.1]
+    flat = np.flatnonzero(ids == 11); pts[flat, 2] = 1.0               # a flat instance: its inner hull cannot be certified
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        x, di = torch.from_numpy(pts).to(dev), torch.from_numpy(ids).to(dev)
+        order = torch.empty(n, dtype=torch.int32, device=dev); keys = torch.empty(n, dtype=torch.int32, device=dev)
+        starts = torch.empty(nids + 2, dtype=torch.int64, device=dev)
+        cand = torch.empty(n, dtype=torch.int32, device=dev); cs = torch.empty(nids + 1, dtype=torch.int64, device=dev)
+        ctx.group_by_id_dev(di.data_ptr(), n, nids, order.data_ptr(), keys.data_ptr(), starts.data_ptr(), s.cuda_stream)
+        ctx.obb_candidates_dev(x.data_ptr(), f3d.F64, n, order.data_ptr(), keys.data_ptr(), starts.data_ptr(), nids, 256, cand.data_ptr(), cs.data_ptr(), s.cuda_stream)
+        s.synchronize()
+    cs, cand = cs.cpu().numpy(), cand.cpu().numpy()
+    assert cs[0] == 0 and (np.diff(cs) >= 0).all()
+    dropped = 0
+    for k in range(nids):
+        mem = np.flatnonzero(ids == k)
+        c = cand[cs[k]:cs[k + 1]]
+        assert np.array_equal(c, np.sort(c)) and set(c.tolist()) <= set(mem.tolist()), k
+        if k in (9, 11) or len(mem) < 256:
+            assert np.array_equal(c, mem), k
+            continue
+        hv = mem[ConvexHull(pts[mem]).vertices]
+        assert set(hv.tolist()) <= set(c.tolist()), k
+        dropped += len(mem) - len(c)
+    assert dropped > 0.5 * n
+
+
 def test_config_c5_merge_50m_points_4096_instances():
-    """C5's merge leg at full size (BASELINE.json config 5): 50M points, 4096 instances.  The oracle cannot afford this size; checked
-    are the count two earlier generations of this code produced for the same seeded scene (profiles/r02_merge_c5_breakdown.md) and
-    that instances really disappear into others.  (No "same parent" property holds: the reference looks parents up by LIST INDEX
-    after entries have been deleted -- quirk Q6/Q7 -- which the drop-in reproduces.)"""
+    """C5's merge leg at full size (BASELINE.json config 5): 50M points, 4096 instances, the product's own GPU fit.  The oracle's
+    O(B^2 N) control flow cannot afford this size (it is compared at 160 instances above); at full size the evidence is a second run
+    of the same scene in which every box comes from ANOTHER implementation of the fit (the oracle's scipy / LAPACK recipe, injected).
+    (No "same parent" property holds: the reference looks parents up by LIST INDEX after entries have been deleted -- quirk
+    Q6/Q7 -- which the drop-in reproduces.)"""
     import time
     from Fusion3DSeg.merge_intersecting_bb import merge_bb
     pts, ids, info = _c5_blobs(4096, 50_000_000)
     before = ids.copy()
     t0 = time.perf_counter()
-    out_info, out_ids = merge_bb(None, info, ids, pts)
+    out_info, out_ids = merge_bb(None, copy.deepcopy(info), ids, pts)
     dt = time.perf_counter() - t0
-    assert len(out_info) == 3964
+    # independent evidence at full size (VERDICT r2): the same scene with the ORACLE's fit (scipy Qhull + LAPACK, on the host) injected
+    # on the hull candidates -- another implementation of every box the control flow asks for -- must merge the same instances
+    ref_info, ref_ids = merge_bb(None, copy.deepcopy(info), before.copy(), pts, box_fn=O.obb_from_points, prefilter=True)
+    assert np.array_equal(out_ids, ref_ids) and [(d['id'], d['area']) for d in out_info] == [(d['id'], d['area']) for d in ref_info]
+    _same_boxes(out_info, ref_info, tol=1e-7)
+    assert len(out_info) < len(info) - 50
     moved = out_ids != before
     assert moved.any() and len(np.unique(out_ids)) < len(np.unique(before))
     boxed = [d for d in out_info[1:] if 'bbox' in d]
