@@ -108,22 +108,38 @@ class HipCloud:
     between the three grouping calls).  `point_range` = the [lo, hi) share of the points this process scans (sharded merge)."""
 
     def __init__(self, pts, point_range=None):
-        self.pts = pts
         self.n = len(pts)
         self.lo, self.hi = (0, self.n) if point_range is None else point_range
         self.ctx = f3d.default_context()
         self.torch = None
+        self._host = None
         try:
             import torch
             if torch.cuda.is_available():
                 self.torch = torch
                 self.device = torch.device('cuda', self.ctx.device)
                 self.stream = torch.cuda.Stream(self.device)
-                with torch.cuda.stream(self.stream):
-                    self.dev = torch.from_numpy(pts).to(self.device)
-                self.stream.synchronize()
+                if torch.is_tensor(pts):                               # a cloud that is already resident (merge_bb_dev): used where it lies
+                    if not (pts.is_cuda and pts.dtype == torch.float64 and pts.is_contiguous() and pts.dim() == 2 and pts.shape[1] == 3):
+                        raise ValueError('a device cloud must be a contiguous float64 CUDA tensor [N, 3]')
+                    self.stream.wait_stream(torch.cuda.current_stream(self.device))
+                    self.dev = pts
+                else:
+                    self._host = pts
+                    with torch.cuda.stream(self.stream):
+                        self.dev = torch.from_numpy(pts).to(self.device)
+                    self.stream.synchronize()
         except ImportError:
             pass
+        if self.torch is None:
+            self._host = pts
+
+    @property
+    def pts(self):
+        """The cloud on the host (downloaded on first use when the caller handed over a device tensor: only the host fallbacks need it)."""
+        if self._host is None:
+            self._host = self.dev.cpu().numpy()
+        return self._host
 
     def group(self, ids, nids):
         """(order int32 [n], starts int64 [nids + 2]) -- members of every id in ascending point index."""
@@ -131,7 +147,8 @@ class HipCloud:
             return self.ctx.group_by_id(ids, nids)
         torch = self.torch
         with torch.cuda.stream(self.stream):
-            dids = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+            resident = torch.is_tensor(ids)
+            dids = ids if resident else torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
             self.d_order = torch.empty(self.n, dtype=torch.int32, device=self.device)
             self.d_keys = torch.empty(self.n, dtype=torch.int32, device=self.device)
             self.d_starts = torch.empty(nids + 2, dtype=torch.int64, device=self.device)
@@ -139,7 +156,34 @@ class HipCloud:
                                      self.stream.cuda_stream)
             self.stream.synchronize()
             self.nids = nids
-            return self.d_order.cpu().numpy(), self.d_starts.cpu().numpy()
+            # resident ids: the member lists stay on the device (nobody relabels a host array); only the segment bounds come back
+            return (None if resident else self.d_order.cpu().numpy()), self.d_starts.cpu().numpy()
+
+    def relabel(self, ids, src, dst):
+        """ids[ids == src] = dst on the device tensor `ids` (update_id_info, merge_intersecting_bb.py:59-61)."""
+        with self.torch.cuda.stream(self.stream):
+            self.ctx.relabel_dev(ids.data_ptr(), self.n, int(src), int(dst), None, self.stream.cuda_stream)
+
+    def fit_indices(self, index_sets):
+        """Boxes of a few instances given as point-index arrays (refits after a merge), gathered and fitted on the device:
+        (boxes [k, 15], status [k])."""
+        torch = self.torch
+        start = np.zeros(len(index_sets) + 1, np.int64)
+        start[1:] = np.cumsum([len(a) for a in index_sets])
+        total = int(start[-1])
+        flat = np.ascontiguousarray(np.concatenate(index_sets), dtype=np.int32) if total else np.zeros(0, np.int32)
+        with torch.cuda.stream(self.stream):
+            didx = torch.from_numpy(flat).to(self.device)
+            dstart = torch.from_numpy(start).to(self.device)
+            cpts = torch.empty((max(total, 1), 3), dtype=torch.float64, device=self.device)
+            boxes = torch.empty((len(index_sets), f3d.OBB_DOUBLES), dtype=torch.float64, device=self.device)
+            status = torch.empty(len(index_sets), dtype=torch.int32, device=self.device)
+            isvert = torch.empty(max(total, 1), dtype=torch.uint8, device=self.device)
+            self.ctx.gather_points_dev(self.dev.data_ptr(), f3d.F64, didx.data_ptr(), total, cpts.data_ptr(), self.stream.cuda_stream)
+            self.ctx.obb_fit_dev(cpts.data_ptr(), dstart.data_ptr(), len(index_sets), total, boxes.data_ptr(), status.data_ptr(), isvert.data_ptr(), None,
+                                 self.stream.cuda_stream)
+            self.stream.synchronize()
+            return boxes.cpu().numpy(), status.cpu().numpy()
 
     def extremes(self):
         if self.torch is None:
@@ -246,7 +290,7 @@ class _MergeState:
         # box_fn None = the built-in fit: on the GPU, instances the kernel defers on the host (obb_from_points).  A caller-supplied
         # box_fn gets exactly pcd_points[ids == id] unless it opts into the hull-candidate prefilter (exact for hull-based fits only).
         self.gpu_fit = box_fn is None
-        self.pts, self.ids, self.box_fn, self.dist = pts, ids, (box_fn or obb_from_points), dist
+        self._pts, self.ids, self.box_fn, self.dist = pts, ids, (box_fn or obb_from_points), dist
         self.use_prefilter = self.gpu_fit if prefilter == 'auto' else bool(prefilter)
         self.prof = {'group': 0.0, 'prefilter': 0.0, 'fit': 0.0, 'nfit': 0, 'nfit_gpu': 0, 'nfit_deferred': 0, 'scan': 0.0, 'nscan': 0, 'absorb': 0.0,
                      'upload': 0.0, 'exchange': 0.0}
@@ -257,18 +301,25 @@ class _MergeState:
         self.cloud = backend(pts, share) if backend is not None else HipCloud(pts, share)
         self.prof['upload'] = time.perf_counter() - t0
         t0 = time.perf_counter()
+        self.resident = not isinstance(ids, np.ndarray)  # merge_bb_dev: ids (and the cloud) are device tensors, relabelled in place on the device
         ids_ok = n > 0 and int(ids.min()) >= 0 and int(ids.max()) < 2 ** 30
+        if self.resident and not ids_ok:
+            raise ValueError('merge_bb_dev: instance ids must lie in [0, 2^30)')
         self.nids = int(ids.max()) + 1 if ids_ok else 0
+        self.members = None
         if ids_ok:
             order, starts = self.cloud.group(ids, self.nids)
-            self.members = {k: [order[starts[k]:starts[k + 1]]] for k in range(self.nids) if starts[k + 1] > starts[k]}
+            if order is not None:
+                self.members = {k: [order[starts[k]:starts[k + 1]]] for k in range(self.nids) if starts[k + 1] > starts[k]}
+            self.counts = {k: int(starts[k + 1] - starts[k]) for k in range(self.nids) if starts[k + 1] > starts[k]}
         else:                                             # negative or huge ids: plain NumPy grouping (no prefilter either)
             order = np.argsort(ids, kind='stable')
             uniq, start = np.unique(ids[order], return_index=True)
             bounds = np.append(start, n)
             self.members = {int(u): [order[bounds[k]:bounds[k + 1]]] for k, u in enumerate(uniq)}
-        self.counts = {k: len(v[0]) for k, v in self.members.items()}
-        self.cands = {k: v[0] for k, v in self.members.items()}       # hull candidates: ascending point indices, a superset of the hull's vertices
+            self.counts = {k: len(v[0]) for k, v in self.members.items()}
+        # hull candidates: ascending point indices, a superset of the hull's vertices
+        self.cands = {k: v[0] for k, v in self.members.items()} if self.members is not None else {}
         self.prof['group'] = time.perf_counter() - t0
         self.boxes, self.failed = {}, {}
         done = False
@@ -293,7 +344,7 @@ class _MergeState:
             return False
         cand, cs, boxes, status = res
         ok = np.flatnonzero(status == f3d.OBB_OK)
-        for k in self.members:
+        for k in self.counts:
             self.cands[k] = cand[cs[k]:cs[k + 1]]
         if len(ok):
             c, R, e = boxes[ok, 0:3], boxes[ok, 3:12].reshape(-1, 3, 3), boxes[ok, 12:15]
@@ -303,7 +354,7 @@ class _MergeState:
             pad = 1e-9 * (np.abs(corners).max(axis=(1, 2)) + np.abs(e).max(axis=1) + 1.0)
             lo, hi = corners.min(1) - pad[:, None], corners.max(1) + pad[:, None]
             for j, k in enumerate(ok):
-                if int(k) in self.members:
+                if int(k) in self.counts:
                     self.boxes[int(k)] = (c[j].copy(), R[j].copy(), e[j].copy(), lo[j], hi[j])
         self.prof['nfit'] += len(ok); self.prof['nfit_gpu'] += len(ok)
         return True
@@ -338,20 +389,32 @@ class _MergeState:
             if nf[k]:
                 self.cands[k] = np.sort(cand[starts[k]:starts[k] + cnt[k]])
 
+    @property
+    def pts(self):
+        """The cloud on the host (a resident cloud is downloaded on first use: only host fallbacks ask for it)."""
+        return self._pts if isinstance(self._pts, np.ndarray) else self.cloud.pts
+
     def count(self, i):
         return self.counts.get(int(i), 0)
 
     def _fit(self, i):
         t0 = time.perf_counter()
-        src = self.pts[self.cands[i]] if (self.use_prefilter or self.gpu_fit) else self.pts[np.sort(np.concatenate(self.members[i]))]
         fitted = None
-        if self.gpu_fit and hasattr(self.cloud, 'fit') and len(src) >= 4:
-            boxes, status = self.cloud.fit([src])
+        if self.gpu_fit and hasattr(self.cloud, 'fit_indices') and getattr(self.cloud, 'torch', None) is not None and len(self.cands[i]) >= 4:
+            boxes, status = self.cloud.fit_indices([self.cands[i]])            # gathered and fitted on the device
             if status[0] == f3d.OBB_OK:
                 fitted = (boxes[0, 0:3].copy(), boxes[0, 3:12].reshape(3, 3).copy(), boxes[0, 12:15].copy())
                 self.prof['nfit_gpu'] += 1
             else:
                 self.prof['nfit_deferred'] += 1
+        if fitted is None:
+            hull_only = self.use_prefilter or self.gpu_fit                      # a caller's box_fn gets pcd_points[ids == id] unless it opted in
+            src = self.pts[self.cands[i]] if hull_only else self.pts[np.sort(np.concatenate(self.members[i]))]
+            if self.gpu_fit and hasattr(self.cloud, 'fit') and getattr(self.cloud, 'torch', 0) is None and len(src) >= 4:
+                boxes, status = self.cloud.fit([src])                          # host-pointer entry (no torch in the process)
+                if status[0] == f3d.OBB_OK:
+                    fitted = (boxes[0, 0:3].copy(), boxes[0, 3:12].reshape(3, 3).copy(), boxes[0, 12:15].copy())
+                    self.prof['nfit_gpu'] += 1
         c, R, e = fitted if fitted is not None else self.box_fn(src)
         corners = obb_corners(c, R, e)
         pad = 1e-9 * (np.abs(corners).max() + np.abs(e).max() + 1.0)           # the in-box test rounds; never prune a touching pair
@@ -393,12 +456,17 @@ class _MergeState:
         """update_id_info's relabel (reference :59-61) on the incremental state."""
         dst, src = int(dst), int(src)
         t0 = time.perf_counter()
-        moved = self.members.pop(src, None)
-        if not moved:
-            return
-        for part in moved:
-            self.ids[part] = dst
-        self.members.setdefault(dst, []).extend(moved)
+        if self.members is None:                                               # resident ids: one relabel pass on the device
+            if src not in self.counts:
+                return
+            self.cloud.relabel(self.ids, src, dst)
+        else:
+            moved = self.members.pop(src, None)
+            if not moved:
+                return
+            for part in moved:
+                self.ids[part] = dst
+            self.members.setdefault(dst, []).extend(moved)
         self.counts[dst] = self.counts.get(dst, 0) + self.counts.pop(src, 0)
         cs = self.cands.pop(src)
         self.cands[dst] = np.sort(np.concatenate([self.cands[dst], cs])) if dst in self.cands else cs   # hull(A u B) has its vertices among both lists
@@ -455,7 +523,8 @@ def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=None, dist=None,
     (GPU, host for the instances the kernel defers); a caller-supplied ``box_fn`` is called on ``pcd_points[ids == id]`` like the
     reference's, or -- ``prefilter=True``, exact for hull-based fits only -- on the instance's hull candidates."""
     n0 = len(info_sem)
-    pts = np.ascontiguousarray(np.asarray(pcd.points if hasattr(pcd, 'points') else pcd), dtype=np.float64)
+    resident = not isinstance(id_info_per_point, np.ndarray) and hasattr(id_info_per_point, 'is_cuda')
+    pts = pcd if resident else np.ascontiguousarray(np.asarray(pcd.points if hasattr(pcd, 'points') else pcd), dtype=np.float64)
     t0 = time.perf_counter()
     id_list = [info_sem[i]["id"] for i in range(len(info_sem))]
     st = _MergeState(pts, id_info_per_point, box_fn, dist, backend, prefilter)
@@ -482,5 +551,18 @@ def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=None, dist=None,
         with open(out / "final_info.json", 'w') as fp:
             json.dump(info_sem, fp, indent=4)
         with open(out / "ids.npy", 'wb') as fi:
-            np.save(fi, id_info_per_point)
+            np.save(fi, id_info_per_point.cpu().numpy() if resident else id_info_per_point)
     return info_sem, id_info_per_point
+
+
+def merge_bb_dev(info_sem, ids, points, dir_name=None, dist=None):
+    """merge_bb on a RESIDENT cloud: ``points`` float64 CUDA tensor [N, 3], ``ids`` int64 CUDA tensor [N] (relabelled in place on
+    the device, like the reference mutates its array).  Nothing of the cloud crosses PCIe: grouping, hull candidates, box fits,
+    scans and relabels run on the tensors where they lie; the host sees the segment bounds, the candidates' indices and the boxes.
+    Same result as merge_bb on the host copies (tests/test_mirror_gpu.py)."""
+    import torch
+    if not (torch.is_tensor(ids) and ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 1):
+        raise ValueError('merge_bb_dev: ids must be a contiguous int64 CUDA tensor [N]')
+    if not (torch.is_tensor(points) and points.is_cuda and len(points) == len(ids)):
+        raise ValueError('merge_bb_dev: points must be a CUDA tensor [N, 3] of the same length as ids')
+    return merge_bb(dir_name, info_sem, ids, points, dist=dist)

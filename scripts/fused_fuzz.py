@@ -50,6 +50,7 @@ def one_config(ctx, rng, k, verbose=True):
     want_votes = V <= 300 and rng.random() < 0.5
     votes = torch.zeros((n, 134), dtype=torch.uint16, device=dev) if want_votes else None
     s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream(dev))        # the fills / copies above run on the current stream
     dt = f3d.F32 if f32 else f3d.F64
     ctx.project_vote_argmax_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, md.data_ptr(), H, W, 133, thr, flt, cls.data_ptr(),
                                 None if votes is None else votes.data_ptr(), s.cuda_stream, flags=flags)
@@ -75,6 +76,7 @@ def one_config(ctx, rng, k, verbose=True):
         ctx.mask_presence_dev(md.data_ptr(), V, H, W, present.data_ptr(), s.cuda_stream)
         ctx.fuse_chunked_begin_dev(present.data_ptr() if rng.random() < 0.7 else None, n, V, H, W, 133, flt, s.cuda_stream)
         cls.fill_(-7)
+        s.wait_stream(torch.cuda.current_stream(dev))
         for a, b in zip(cuts[:-1], cuts[1:]):
             ctx.fuse_chunk_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, a, b, md.data_ptr(), H, W, 133, thr, flt, cls.data_ptr(), s.cuda_stream, flags=flags)
         ctx.take_device_error(s.cuda_stream)

@@ -300,6 +300,7 @@ def _dev_fuse(ctx, pts, views, masks, flt, thr, flags, presort=False, f32=False,
     cls = torch.full((n,), -7, dtype=torch.int64, device=dev)
     votes = torch.full((n, nclasses + 1), 0xFFFF, dtype=torch.uint16, device=dev) if votes_at is not None else None
     s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream(dev))        # the fills / copies above run on the current stream: torch streams do not wait for it by themselves
     dt = f3d.F32 if f32 else f3d.F64
     with torch.cuda.stream(s):
         perm_ptr = None
@@ -566,6 +567,7 @@ def _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, flags, bounds, f32=False
     s = torch.cuda.Stream(dev)
     dt = f3d.F32 if f32 else f3d.F64
     present = torch.empty(256, dtype=torch.uint8, device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))        # (see _dev_fuse)
     with torch.cuda.stream(s):
         if presence == 'own':
             ctx.mask_presence_dev(md.data_ptr(), V, H, W, present.data_ptr(), s.cuda_stream)

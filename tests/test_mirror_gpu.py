@@ -444,6 +444,33 @@ def test_merge_bb_c5_recipe_with_the_oracles_fit_and_prefilter_off():
     assert np.array_equal(a_ids, b_ids) and json.dumps(a_info) == json.dumps(b_info) and len(a_info) < len(info)
 
 
+def test_merge_bb_dev_on_a_resident_cloud_equals_merge_bb():
+    """merge_bb_dev: cloud and ids are device tensors; ids are relabelled in place on the device (f3d_relabel_dev), the refits gather
+    their candidates on the device.  Same entries, same ids as merge_bb on the host copies; the host copy of the cloud is never made."""
+    import torch
+    import Fusion3DSeg.merge_intersecting_bb as M
+    dev = torch.device('cuda', 0)
+    pts, ids, info = _c5_blobs(200, 120_000, seed=5)
+    want_info, want_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts)
+    dp, di = torch.from_numpy(pts).to(dev), torch.from_numpy(ids).to(dev)
+    prof = {}
+    keep = M._MergeState.__init__
+
+    def spy(self, *a, **k):
+        keep(self, *a, **k)
+        prof['st'] = self
+    M._MergeState.__init__ = spy
+    try:
+        got_info, got_ids = M.merge_bb_dev(copy.deepcopy(info), di, dp)
+    finally:
+        M._MergeState.__init__ = keep
+    assert got_ids.data_ptr() == di.data_ptr() and np.array_equal(di.cpu().numpy(), want_ids)
+    assert json.dumps(got_info) == json.dumps(want_info) and len(got_info) < len(info)
+    assert prof['st'].cloud._host is None and prof['st'].members is None           # nothing of the cloud came to the host
+    with pytest.raises(ValueError):
+        M.merge_bb_dev(copy.deepcopy(info), di.to(torch.int32), dp)
+
+
 def test_obb_fit_kernel_hull_vertices_and_boxes():
     """f3d_obb_fit: the hull vertex set equals scipy's Qhull (ConvexHull(...).vertices) on every set the kernel certifies; the box
     equals the oracle's recipe (hull -> PCA -> extents; LAPACK eigh) up to the axis signs: centre / extent within 1e-9 relative,
