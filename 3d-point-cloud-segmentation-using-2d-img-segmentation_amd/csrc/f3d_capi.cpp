@@ -417,6 +417,17 @@ int f3d_unproject_depth_dev(f3d_ctx* ctx, const void* depth, int depth_type, int
     return F3D_OK;
 }
 
+int f3d_unproject_depth_batch_dev(f3d_ctx* ctx, const void* depth, int depth_type, int nframes, int h, int w, const double K[9], double depth_scale,
+                                  const double* q_wxyz, const double* t, double* xyz, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (nframes < 0 || h < 0 || w < 0 || !K || (depth_type != F3D_DEPTH_U16 && depth_type != F3D_DEPTH_F32 && depth_type != F3D_DEPTH_F64) ||
+        (nframes > 0 && (!q_wxyz || !t)) || ((int64_t)nframes * h * w > 0 && (!depth || !xyz)))
+        return fail(ctx, F3D_ERR_INVALID, "unproject_depth_batch: bad arguments");
+    if (nframes == 0) return F3D_OK;
+    F3D_HIP(ctx, f3d_launch_unproject_depth_batch(depth, depth_type, nframes, h, w, K, depth_scale, q_wxyz, t, xyz, pick(ctx, stream)));
+    return F3D_OK;
+}
+
 int f3d_unproject_depth(f3d_ctx* ctx, const void* depth, int depth_type, int h, int w, const double K[9], double depth_scale,
                         const double q_wxyz[4], const double t[3], double* xyz) {
     int rc = enter(ctx); if (rc) return rc;
@@ -918,10 +929,10 @@ int f3d_points_in_obb_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_
         return fail(ctx, F3D_ERR_INVALID, "points_in_obb: bad arguments (at most %d boxes per call)", F3D_OBB_MAX_BOXES);
     if (b == 0) return F3D_OK;
     hipStream_t s = pick(ctx, stream);
-    void* dboxes;
-    if ((rc = ensure(ctx, SLOT_VIEWS, sizeof(f3d_obb) * (size_t)b, &dboxes))) return rc;
+    void* dboxes;                                              // the boxes, then their float32 bounds
+    if ((rc = ensure(ctx, SLOT_VIEWS, (sizeof(f3d_obb) + 6 * sizeof(float)) * (size_t)b, &dboxes))) return rc;
     F3D_HIP(ctx, hipMemcpyAsync(dboxes, boxes, sizeof(f3d_obb) * (size_t)b, hipMemcpyHostToDevice, s));
-    F3D_HIP(ctx, f3d_launch_points_in_obb(xyz, dtype, n, (const f3d_obb*)dboxes, b, inside_bits, cooc, s));
+    F3D_HIP(ctx, f3d_launch_points_in_obb(xyz, dtype, n, (const f3d_obb*)dboxes, b, (float*)((char*)dboxes + sizeof(f3d_obb) * (size_t)b), inside_bits, cooc, s));
     return F3D_OK;
 }
 

@@ -138,8 +138,11 @@ hipError_t f3d_launch_vote_uv2pt_batch(const int32_t* luts, const uint8_t* masks
                                        int ncols, unsigned long long* table, uint64_t table_slots, unsigned gen, int frame0, int* first_bad,
                                        int* err, hipStream_t s);
 hipError_t f3d_launch_sem_to_mask(const float* sem, int nimg, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s);
-hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, uint32_t* bits,
+// aabb: float [6 * b] of device scratch (the boxes' padded float32 bounds, filled by the launch)
+hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, float* aabb, uint32_t* bits,
                                     uint8_t* cooc, hipStream_t s);
+hipError_t f3d_launch_unproject_depth_batch(const void* depth, int depth_type, int nframes, int h, int w, const double K[9], double scale,
+                                            const double* q_host, const double* t_host, double* out, hipStream_t s);
 hipError_t f3d_launch_relabel(int64_t* ids, int64_t n, int64_t from, int64_t to, unsigned long long* count, hipStream_t s);
 
 // merge_bb support (f3d_obb.hip): grouping of the points by instance id, extreme members along 26 directions, inner-hull filter

@@ -59,6 +59,32 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_unproject_depth(const D* __restri
     }
 }
 
+// up to F3D_UNPROJECT_BATCH frames in one launch (blockIdx.y = frame): a 1024 x 1024 frame alone is launch-bound (11 us for 27 MB).
+// The poses (q (w, x, y, z) then t per frame) travel in the kernel argument block: no staging buffer, no synchronisation.
+#define F3D_UNPROJECT_BATCH 64
+struct pose_batch { double p[F3D_UNPROJECT_BATCH][7]; };
+template <typename D>
+__global__ __launch_bounds__(F3D_BLOCK) void k_unproject_depth_batch(const D* __restrict__ depth, int h, int w, unproject_arg a,
+                                                                      pose_batch poses, double* __restrict__ out) {
+    const int64_t n = (int64_t)h * w;
+    const double* ps = poses.p[blockIdx.y];
+    double q[4] = {ps[0], ps[1], ps[2], ps[3]};
+    const double t0 = ps[4], t1 = ps[5], t2 = ps[6];
+    depth += (size_t)blockIdx.y * n;
+    out += 3 * (size_t)blockIdx.y * n;
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK) {
+        const int64_t row = i / w;
+        const double px = (double)(i - row * w), py = (double)row;
+        const double d = (double)depth[i];
+        f3d_p3 c;
+        c.x = ((px - a.cx) * (d / a.fx)) / a.scale;
+        c.y = ((py - a.cy) * (d / a.fy)) / a.scale;
+        c.z = d / a.scale;
+        const f3d_p3 o = f3d_rotate(q, c);
+        out[3 * i] = o.x + t0; out[3 * i + 1] = o.y + t1; out[3 * i + 2] = o.z + t2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // a2 (+a4): one view, streaming.  24 B (f64) or 12 B (f32) in, 8 B uv + 1 B inside out per point.
 // The view record arrives in the kernarg segment -> SGPRs (wave-uniform).
@@ -365,9 +391,36 @@ __device__ __forceinline__ void pin(obb_consts& o) {
     for (int k = 0; k < 9; ++k) asm volatile("" : "+s"(o.R[k]));
 }
 
+// float32 bounds of box k, padded so that a point outside them is certainly outside the box: aabb[k] = lo[3], hi[3].
+// The box is {p : |R^T (p - c)|_a <= e_a / 2}: p - c = (R^T)^-1 y with |y_a| <= e_a / 2, so the half width along world axis i is
+// sum_a |(R^T)^-1[i][a]| e_a / 2 (= sum_a |R[i][a]| e_a / 2 for the orthonormal R of a fitted box; any other R is handled too, a
+// singular one gets infinite bounds: the exact test alone decides).
+__global__ __launch_bounds__(F3D_BLOCK) void k_obb_aabb(const f3d_obb* __restrict__ boxes, int B, float* __restrict__ aabb) {
+    const int k = blockIdx.x * F3D_BLOCK + threadIdx.x;
+    if (k >= B) return;
+    const f3d_obb b = boxes[k];
+    // M = R^T: M[a][i] = R[3 i + a]
+    const double m00 = b.R[0], m01 = b.R[3], m02 = b.R[6], m10 = b.R[1], m11 = b.R[4], m12 = b.R[7], m20 = b.R[2], m21 = b.R[5], m22 = b.R[8];
+    const double c00 = m11 * m22 - m12 * m21, c01 = m02 * m21 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+    const double c10 = m12 * m20 - m10 * m22, c11 = m00 * m22 - m02 * m20, c12 = m02 * m10 - m00 * m12;
+    const double c20 = m10 * m21 - m11 * m20, c21 = m01 * m20 - m00 * m21, c22 = m00 * m11 - m01 * m10;
+    const double det = m00 * c00 + m01 * c10 + m02 * c20;
+    const double inv[3][3] = {{c00 / det, c01 / det, c02 / det}, {c10 / det, c11 / det, c12 / det}, {c20 / det, c21 / det, c22 / det}};
+    const double scale = fabs(m00) + fabs(m01) + fabs(m02) + fabs(m10) + fabs(m11) + fabs(m12) + fabs(m20) + fabs(m21) + fabs(m22);
+    const bool usable = fabs(det) > 1e-9 * scale * scale * scale;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double h = (fabs(inv[i][0]) * fabs(b.extent[0]) + fabs(inv[i][1]) * fabs(b.extent[1]) + fabs(inv[i][2]) * fabs(b.extent[2])) * 0.5;
+        const double pad = 1e-6 * (fabs(b.center[i]) + h) + 1e-30;        // float32 rounding of the point and of the bounds, the in-box test's own rounding
+        float lo = (float)(b.center[i] - h - pad), hi = (float)(b.center[i] + h + pad);
+        if (!usable || !(h == h) || !(lo <= hi)) { lo = -INFINITY; hi = INFINITY; }      // the exact test alone decides
+        aabb[6 * k + i] = lo; aabb[6 * k + 3 + i] = hi;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb(const T* __restrict__ xyz, int64_t n,
-                                                              const f3d_obb* __restrict__ boxes, int B,
+                                                              const f3d_obb* __restrict__ boxes, int B, const float* __restrict__ aabb,
                                                               uint32_t* __restrict__ bits, uint8_t* __restrict__ cooc) {
     extern __shared__ uint32_t obb_lds[];                   // [words][F3D_BLOCK] bitset of this tile's points
     const int words = (B + 31) >> 5;
@@ -381,27 +434,27 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb(const T* __restrict
         if (live) p = load_point(xyz, i);
         uint32_t any = 0;
         // the boxes are wave-uniform: scalar loads straight from global memory (SGPR operands).  Staging them in LDS made the
-        // kernel LDS-bound (15 broadcast 8-B reads per point-box test against ~25 VALU instructions); two boxes are requested
-        // and pinned together so that one scalar-memory round trip covers both
+        // kernel LDS-bound (15 broadcast 8-B reads per point-box test against ~25 VALU instructions).
+        // Pre-test per (wave, box): six float32 compares against the box's padded axis-aligned bounds; the float64 in-box test (27
+        // flop) runs only for a wave with a point inside those bounds -- for boxes that are small against the scene almost never.
+        const float px = (float)p.x, py = (float)p.y, pz = (float)p.z;
         for (int w0 = 0; w0 < B; w0 += 32) {
             uint32_t word = 0;
             const int lim = min(32, B - w0);
-            for (int k = 0; k < lim; k += 2) {
-                obb_consts bx[2];
-                bx[0] = load_obb(boxes[w0 + k]);
-                bx[1] = load_obb(boxes[w0 + min(k + 1, lim - 1)]);
-                pin(bx[0]); pin(bx[1]);
+            for (int k = 0; k < lim; ++k) {                             // (four boxes' bounds per scalar round trip, pinned: measured slower, 0.44 vs 0.36 ms)
+                const float* ab = aabb + 6 * (size_t)(w0 + k);
+                const bool near = live & (px >= ab[0]) & (py >= ab[1]) & (pz >= ab[2]) & (px <= ab[3]) & (py <= ab[4]) & (pz <= ab[5]);
+                if (!__any(near)) continue;                              // wave-uniform: a scalar branch
+                obb_consts bx = load_obb(boxes[w0 + k]);
+                pin(bx);
+                const double d0 = p.x - bx.c[0], d1 = p.y - bx.c[1], d2 = p.z - bx.c[2];
+                bool in = near;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const double d0 = p.x - bx[u].c[0], d1 = p.y - bx[u].c[1], d2 = p.z - bx[u].c[2];
-                    bool in = live & (k + u < lim);
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const double pr = (d0 * bx[u].R[a] + d1 * bx[u].R[3 + a]) + d2 * bx[u].R[6 + a];
-                        in = in & (fabs(pr) <= bx[u].e[a] / 2);
-                    }
-                    word |= in ? (1u << ((k + u) & 31)) : 0u;
+                for (int a = 0; a < 3; ++a) {
+                    const double pr = (d0 * bx.R[a] + d1 * bx.R[3 + a]) + d2 * bx.R[6 + a];
+                    in = in & (fabs(pr) <= bx.e[a] / 2);
                 }
+                word |= in ? (1u << (k & 31)) : 0u;
             }
             myb[(w0 >> 5) * F3D_BLOCK + tid] = word;
             any |= word;
@@ -488,6 +541,34 @@ hipError_t f3d_launch_unproject_depth(const void* depth, int depth_type, int h, 
     return hipGetLastError();
 }
 
+hipError_t f3d_launch_unproject_depth_batch(const void* depth, int depth_type, int nframes, int h, int w, const double K[9], double scale,
+                                            const double* q_host, const double* t_host, double* out, hipStream_t s) {
+    const int64_t n = (int64_t)h * w;
+    if (n <= 0 || nframes <= 0) return hipSuccess;
+    unproject_arg a;
+    a.fx = K[0]; a.fy = K[4]; a.cx = K[2]; a.cy = K[5]; a.scale = scale;
+    for (int k = 0; k < 4; ++k) a.q[k] = 0.0;
+    for (int k = 0; k < 3; ++k) a.t[k] = 0.0;
+    const size_t esz = depth_type == F3D_DEPTH_U16 ? 2 : depth_type == F3D_DEPTH_F32 ? 4 : 8;
+    for (int f0 = 0; f0 < nframes; f0 += F3D_UNPROJECT_BATCH) {
+        const int nf = nframes - f0 < F3D_UNPROJECT_BATCH ? nframes - f0 : F3D_UNPROJECT_BATCH;
+        pose_batch pb;
+        for (int f = 0; f < nf; ++f) {
+            for (int k = 0; k < 4; ++k) pb.p[f][k] = q_host[4 * (size_t)(f0 + f) + k];
+            for (int k = 0; k < 3; ++k) pb.p[f][4 + k] = t_host[3 * (size_t)(f0 + f) + k];
+        }
+        const int cap = (F3D_GRID_CAP + nf - 1) / nf;
+        const dim3 g(grid_for(n, F3D_BLOCK, cap < 64 ? 64 : cap), nf), b(F3D_BLOCK);
+        const char* din = reinterpret_cast<const char*>(depth) + (size_t)f0 * n * esz;
+        double* dout = out + 3 * (size_t)f0 * n;
+        if (depth_type == F3D_DEPTH_U16) hipLaunchKernelGGL(k_unproject_depth_batch<uint16_t>, g, b, 0, s, (const uint16_t*)din, h, w, a, pb, dout);
+        else if (depth_type == F3D_DEPTH_F32) hipLaunchKernelGGL(k_unproject_depth_batch<float>, g, b, 0, s, (const float*)din, h, w, a, pb, dout);
+        else if (depth_type == F3D_DEPTH_F64) hipLaunchKernelGGL(k_unproject_depth_batch<double>, g, b, 0, s, (const double*)din, h, w, a, pb, dout);
+        else return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t f3d_launch_project_view(const void* xyz, int dtype, int64_t n, const f3d_view& vw, int32_t* uv, uint8_t* inside,
                                    hipStream_t s) {
     if (n <= 0) return hipSuccess;
@@ -558,10 +639,11 @@ hipError_t f3d_launch_sem_to_mask(const float* sem, int nimg, int c, int64_t hw,
     return hipGetLastError();
 }
 
-hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, uint32_t* bits,
+hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, float* aabb, uint32_t* bits,
                                     uint8_t* cooc, hipStream_t s) {
     if (n <= 0 || b <= 0) return hipSuccess;
     if (b > F3D_OBB_MAX_BOXES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_obb_aabb, dim3((b + F3D_BLOCK - 1) / F3D_BLOCK), dim3(F3D_BLOCK), 0, s, boxes_dev, b, aabb);
     if (cooc) {
         hipError_t e = hipMemsetAsync(cooc, 0, (size_t)b * b, s);
         if (e != hipSuccess) return e;
@@ -574,13 +656,13 @@ hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const
             hipError_t e = hipFuncSetAttribute((const void*)k_points_in_obb<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_points_in_obb<double>, g, blk, lds, s, (const double*)xyz, n, boxes_dev, b, bits, cooc);
+        hipLaunchKernelGGL(k_points_in_obb<double>, g, blk, lds, s, (const double*)xyz, n, boxes_dev, b, aabb, bits, cooc);
     } else {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)k_points_in_obb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_points_in_obb<float>, g, blk, lds, s, (const float*)xyz, n, boxes_dev, b, bits, cooc);
+        hipLaunchKernelGGL(k_points_in_obb<float>, g, blk, lds, s, (const float*)xyz, n, boxes_dev, b, aabb, bits, cooc);
     }
     return hipGetLastError();
 }

@@ -371,7 +371,7 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     sort_key_t* keys = reinterpret_cast<sort_key_t*>(base + L.keys);
     uint32_t* hist = reinterpret_cast<uint32_t*>(base + L.hist);
     const int64_t gb = (n + SB - 1) / SB;
-    const int64_t stride = n > (1 << 18) ? n >> 18 : 1;          // inspect <= ~262k points for the bounding box
+    const int64_t stride = n > (1 << 16) ? n >> 16 : 1;          // inspect <= ~65k points for the bounding box (4 strided loads per thread of 64 blocks)
     const int64_t sb = ((n + stride - 1) / stride + SB - 1) / SB;
     const int nparts = (int)(sb < 64 ? sb : 64);                 // (one lane of k_rs_keys' first wave per partial box)
     const int gstream = (int)(gb < 8192 ? gb : 8192);

@@ -129,6 +129,7 @@ def library():
         'f3d_patch_seeds_sums': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, dbl, dbl, vp, vp, vp, vp]),
         'f3d_unproject_depth': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp]),
         'f3d_unproject_depth_dev': (i32, [vp, vp, i32, i32, i32, vp, dbl, vp, vp, vp, vp]),
+        'f3d_unproject_depth_batch_dev': (i32, [vp, vp, i32, i32, i32, i32, vp, dbl, vp, vp, vp, vp]),
         'f3d_radius_graph_count': (i32, [vp, vp, i32, i64, dbl, vp, vp]),
         'f3d_radius_graph_fill': (i32, [vp, i64, vp]),
         'f3d_radius_graph_count_dev': (i32, [vp, vp, i32, i64, dbl, vp, vp, vp]),
@@ -675,6 +676,12 @@ class Context:
 
     def obb_fit_dev(self, pts_ptr, start_ptr, nfit, total, boxes_ptr, status_ptr, isvert_ptr, nvert_ptr=None, stream=None):
         self._check(self._lib.f3d_obb_fit_dev(self._h, pts_ptr, start_ptr, int(nfit), int(total), boxes_ptr, status_ptr, isvert_ptr, nvert_ptr, stream))
+
+    def unproject_depth_batch_dev(self, depth_ptr, depth_code, nframes, h, w, K, q_wxyz, t, out_ptr, depth_scale=1000.0, stream=None):
+        """F depth frames [F,h,w] on the device -> world points float64 [F,h*w,3] in one launch; q_wxyz [F,4], t [F,3] host arrays."""
+        K, q, t = _f64(K, (3, 3)), _f64(q_wxyz, (int(nframes), 4)), _f64(t, (int(nframes), 3))
+        self._check(self._lib.f3d_unproject_depth_batch_dev(self._h, depth_ptr, int(depth_code), int(nframes), int(h), int(w), _ptr(K), float(depth_scale),
+                                                            _ptr(q), _ptr(t), out_ptr, stream))
 
     def relabel_dev(self, ids_ptr, n, from_id, to_id, count_ptr=None, stream=None):
         self._check(self._lib.f3d_relabel_dev(self._h, ids_ptr, n, int(from_id), int(to_id), count_ptr, stream))

@@ -644,7 +644,14 @@ def main():
         b = 26 * S * S
         extras['unproject_depth ((f)#3, 1024x1024 u16 frame)'] = dict(ms=round(tk * 1e3, 4), GBps=round(b / tk / 1e9, 1), hbm_frac=round(b / tk / 1e9 / HBM_PEAK_GBS, 4),
                                                                        bytes_per_pixel=26)
-        del dep, wpts
+        Fd = 16                                              # the same as ONE launch over 16 frames
+        depb = torch.randint(0, 6000, (Fd, S, S), device=dev, dtype=torch.int16)
+        wptb = torch.empty((Fd, S * S, 3), dtype=torch.float64, device=dev)
+        qb, tb = np.tile(qd, (Fd, 1)), np.tile(td, (Fd, 1))
+        tkb = time_kernel(torch, lambda: ctx.unproject_depth_batch_dev(depb.data_ptr(), 2, Fd, S, S, Kd, qb, tb, wptb.data_ptr(), 1000.0, stream.cuda_stream), 5, stream) / Fd
+        extras['unproject_depth ((f)#3, 1024x1024 u16 frame)'].update(batched_ms_per_frame=round(tkb * 1e3, 4), GBps_batched=round(b / tkb / 1e9, 1),
+                                                                     hbm_frac_batched=round(b / tkb / 1e9 / HBM_PEAK_GBS, 4), frames_per_batch=Fd)
+        del dep, wpts, depb, wptb
         # a10/a11: all points x 64 oriented boxes, membership co-occurrence only
         boxes = np.zeros((64, 15)); boxes[:, 0:3] = rng.uniform([-5, -5, 0], [5, 5, 3], (64, 3))
         boxes[:, 3:12] = np.eye(3).reshape(-1); boxes[:, 12:15] = 0.8
@@ -652,7 +659,7 @@ def main():
         tk = time_kernel(torch, lambda: ctx.points_in_obb_dev(xyz.data_ptr(), dtype, n, boxes, None, cooc.data_ptr(), stream.cuda_stream), 5, stream)
         extras['points_in_obb (a10/a11, 64 boxes)'] = dict(ms=round(tk * 1e3, 4), point_box_tests_per_s=round(64 * n / tk, 1),
                                                            GBps=round(xyz_b * n / tk / 1e9, 1), hbm_frac=round(xyz_b * n / tk / 1e9 / HBM_PEAK_GBS, 4),
-                                                           note='fp64-VALU bound beyond ~8 boxes (27 flop per point-box test); brute force over boxes')
+                                                           note='per (wave, box) a float32 test against the box bounds first; the float64 in-box test (27 flop) only for waves with a point inside them')
         del ins, cooc
         out['streaming_kernels'] = extras
 

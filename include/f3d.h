@@ -451,6 +451,11 @@ int f3d_unproject_depth(f3d_ctx* ctx, const void* depth, int depth_type, int h, 
                         double depth_scale, const double q_wxyz[4], const double t[3], double* xyz /*[h*w*3]*/);
 int f3d_unproject_depth_dev(f3d_ctx* ctx, const void* depth, int depth_type, int h, int w, const double K[9],
                             double depth_scale, const double q_wxyz[4], const double t[3], double* xyz, void* stream);
+/* F frames per launch (a single 1024 x 1024 frame is launch-bound): depth [F, h, w], q_wxyz host [F, 4], t host [F, 3] ->
+ * xyz float64 [F, h*w, 3].  The poses travel in the kernel argument block, 64 frames per launch: enqueue only, no staging. */
+int f3d_unproject_depth_batch_dev(f3d_ctx* ctx, const void* depth, int depth_type, int nframes, int h, int w,
+                                  const double K[9], double depth_scale, const double* q_wxyz, const double* t,
+                                  double* xyz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,19 @@ def test_points_in_obb_large_and_ragged_box_counts(B):
     m = inside.astype(np.float32)
     assert np.array_equal(cooc, (m.T @ m) > 0)
     assert inside.any(0).mean() > 0.5
+    # boxes whose R is NOT orthonormal (sheared, scaled, one singular, one NaN), huge and tiny extents: the float32 bounds of the
+    # pre-test must never hide a point the in-box test accepts
+    odd = boxes[:16].copy()
+    for k in range(16):
+        odd[k, 3:12] = (boxes[k, 3:12].reshape(3, 3) @ (np.eye(3) + rng.normal(size=(3, 3)) * 0.4) * rng.uniform(0.3, 3.0)).reshape(-1)
+    odd[3, 3:12] = np.array([[1, 2, 3], [2, 4, 6], [0, 0, 1.0]]).reshape(-1)          # singular
+    odd[5, 12:15] = [1e6, 1e-9, 2.0]
+    odd[7, 3] = np.nan
+    with np.errstate(all='ignore'):
+        inside2, _ = ctx.points_in_obb(pts, odd)
+        for k in range(16):
+            assert np.array_equal(inside2[:, k], O.points_in_obb(pts, odd[k, 0:3], odd[k, 3:12].reshape(3, 3), odd[k, 12:15])), k
+    assert inside2[:, :3].any()
 
 
 def _rank_labels(rank, world, port, n, out_dir):

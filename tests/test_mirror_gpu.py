@@ -716,6 +716,28 @@ def test_unproject_depth_matches_oracle_bit_for_bit():
     assert f3d.default_context().unproject_depth(np.zeros((0, 5), np.uint16), K, [1, 0, 0, 0], [0, 0, 0]).shape == (0, 3)
 
 
+def test_unproject_depth_batch_equals_frame_by_frame():
+    """f3d_unproject_depth_batch_dev: F frames in one launch = F single-frame calls = the oracle, bit for bit (every depth type)."""
+    import torch
+    dev = torch.device('cuda', 0)
+    ctx = f3d.default_context()
+    rng = np.random.default_rng(41)
+    F, h, w = 5, 48, 67
+    K = np.array([[210.0, 0, w / 2], [0, 205.0, h / 2], [0, 0, 1]])
+    q, t = rng.normal(size=(F, 4)) * 1.2, rng.normal(size=(F, 3))
+    for code, d in [(2, rng.integers(0, 6000, (F, h, w)).astype(np.uint16)), (1, rng.uniform(0, 6, (F, h, w)).astype(np.float32)),
+                    (0, rng.uniform(0, 6, (F, h, w)))]:
+        want = np.stack([O.unproject_depth(d[f], K, q[f], t[f]) for f in range(F)])
+        dd = torch.from_numpy(d.view(np.int16) if code == 2 else d).to(dev)
+        out = torch.empty((F, h * w, 3), dtype=torch.float64, device=dev)
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        ctx.unproject_depth_batch_dev(dd.data_ptr(), code, F, h, w, K, q, t, out.data_ptr(), 1000.0, s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want), code
+        assert np.array_equal(want[2], ctx.unproject_depth(d[2], K, q[2], t[2]))
+
+
 def test_unproject_depth_matches_reference_golden(golden):
     """(f)#3 against the reference's own __getModP3d output (tests/golden/make_golden_rtab.py)."""
     from RTAB_utils.ios_rtab import frames_points_world
