@@ -632,15 +632,46 @@ int f3d_fuse_chunked_begin_dev(f3d_ctx* ctx, const uint8_t* present256, int64_t 
     return F3D_OK;
 }
 
+int f3d_code_planes_dev(f3d_ctx* ctx, const uint8_t* masks, int nplanes, int h, int w, uint8_t* coded, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (!ctx->chunk.active || ctx->chunk.h != h || ctx->chunk.w != w)
+        return fail(ctx, F3D_ERR_INVALID, "code_planes: no view-chunked call with masks of %d x %d is in progress (f3d_fuse_chunked_begin_dev first)", h, w);
+    if (nplanes < 0 || (nplanes > 0 && (!masks || !coded)) || ((uintptr_t)coded & 7)) return fail(ctx, F3D_ERR_INVALID, "code_planes: bad arguments (coded: 8-byte aligned)");
+    F3D_HIP(ctx, f3d_launch_code_planes(masks, coded, nplanes, h, w, ctx->codebook, pick(ctx, stream)));
+    return F3D_OK;
+}
+
+static int fuse_chunk_impl(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews, int v_begin, int v_end,
+                           const uint8_t* masks, const uint8_t* coded, int h, int w, int nclasses, const int32_t* filter, int nfilter, double threshold,
+                           int64_t* classes, unsigned flags, const int32_t* perm, void* stream);
+
 int f3d_fuse_chunk_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews, int v_begin, int v_end,
                        const uint8_t* masks, int h, int w, int nclasses, const int32_t* filter, int nfilter, double threshold,
                        int64_t* classes, unsigned flags, const int32_t* perm, void* stream) {
     int rc = enter(ctx); if (rc) return rc;
+    if (!masks) return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: bad arguments");
+    return fuse_chunk_impl(ctx, xyz, dtype, n, views_dev, nviews, v_begin, v_end, masks, nullptr, h, w, nclasses, filter, nfilter, threshold, classes, flags, perm, stream);
+}
+
+int f3d_fuse_chunk_coded_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews, int v_begin, int v_end,
+                             const uint8_t* coded, int h, int w, int nclasses, const int32_t* filter, int nfilter, double threshold,
+                             int64_t* classes, unsigned flags, const int32_t* perm, void* stream) {
+    int rc = enter(ctx); if (rc) return rc;
+    if (!coded || ((uintptr_t)coded & 7)) return fail(ctx, F3D_ERR_INVALID, "fuse_chunk_coded: bad arguments (coded: 8-byte aligned)");
+    return fuse_chunk_impl(ctx, xyz, dtype, n, views_dev, nviews, v_begin, v_end, nullptr, coded, h, w, nclasses, filter, nfilter, threshold, classes, flags, perm, stream);
+}
+
+// masks: raw planes [nviews, H, W], coded here into context scratch -- or coded: planes some rank coded already (f3d_code_planes_dev with the
+// same book), [nviews] x f3d_coded_plane_bytes, used where they lie
+static int fuse_chunk_impl(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews, int v_begin, int v_end,
+                           const uint8_t* masks, const uint8_t* coded, int h, int w, int nclasses, const int32_t* filter, int nfilter, double threshold,
+                           int64_t* classes, unsigned flags, const int32_t* perm, void* stream) {
+    int rc;
     if (!ctx->chunk.active || ctx->chunk.next != v_begin || ctx->chunk.nviews != nviews || ctx->chunk.h != h || ctx->chunk.w != w ||
         ctx->chunk.nclasses != nclasses || ctx->chunk.n != n || v_end <= v_begin || v_end > nviews)
         return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: views [%d, %d) do not continue the call begun with f3d_fuse_chunked_begin_dev "
                     "(next view %d of %d, same n / h / w / nclasses required)", v_begin, v_end, ctx->chunk.active ? ctx->chunk.next : -1, ctx->chunk.nviews);
-    if (!classes || (n > 0 && !xyz) || !views_dev || !masks) return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: bad arguments");
+    if (!classes || (n > 0 && !xyz) || !views_dev) return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: bad arguments");
     if ((flags & F3D_FUSE_SORT) && perm) return fail(ctx, F3D_ERR_INVALID, "fuse_chunk: F3D_FUSE_SORT and perm are exclusive");
     hipStream_t s = pick(ctx, stream);
     f3d_filter_args fa;
@@ -670,7 +701,8 @@ int f3d_fuse_chunk_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n
     if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews), &tables))) return rc;
     if ((rc = ensure(ctx, SLOT_FUSE_CARRY, f3d_fuse_carry_bytes(n, nclasses), &carry))) return rc;
     const size_t plane = f3d_coded_masks_bytes(1, h, w);
-    F3D_HIP(ctx, f3d_launch_code_planes(masks + (size_t)v_begin * h * w, (uint8_t*)tm + (size_t)v_begin * plane, v_end - v_begin, h, w, ctx->codebook, s));
+    if (coded) tm = const_cast<uint8_t*>(coded);                // the exchange delivered coded planes: no coding, no raw masks, the exact tier reads codes
+    else F3D_HIP(ctx, f3d_launch_code_planes(masks + (size_t)v_begin * h * w, (uint8_t*)tm + (size_t)v_begin * plane, v_end - v_begin, h, w, ctx->codebook, s));
     F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, v_begin, v_end, tables, ctx->codebook, threshold, v_begin == 0 ? (unsigned int*)todo : nullptr, s));
     F3D_HIP(ctx, f3d_launch_fuse(cxyz, dtype, n, views_dev, nviews, masks, (const uint8_t*)tm, h, w, nclasses, fa, threshold, classes, nullptr,
                                  ctx->dev_err, ctx->chunk.perm, cgather, (unsigned int*)todo, (int32_t*)((char*)todo + 16),

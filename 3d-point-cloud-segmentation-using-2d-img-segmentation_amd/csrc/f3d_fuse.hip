@@ -1092,7 +1092,10 @@ __device__ __forceinline__ bool project_fast(const f3d_view& vw, double umax, f3
     return safe & ((unsigned)iu < (unsigned)W) & ((unsigned)iv < (unsigned)H);
 }
 
-template <typename T, bool WRITE_VOTES>
+// EXACT: the last tier of a call that only has CODED masks (the planes of the other ranks arrived coded: f3d_fuse_chunk_coded_dev):
+// the reference's arithmetic (exact 5-plane test, canonical projection, IEEE divisions) on the coded planes, bins and segment as
+// in the other tiers; nothing is deferred further.
+template <typename T, bool WRITE_VOTES, bool EXACT = false>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xyz, const unsigned int* __restrict__ in_count, const int32_t* __restrict__ in_list,
                                                          const f3d_view* __restrict__ views, int nviews,
                                                          const uint8_t* __restrict__ cmasks, int H, int W,
@@ -1125,28 +1128,36 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
         const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
         const bool small = pscale < 1.0e30;
         const float px32 = (float)p.x, py32 = (float)p.y, pz32 = (float)p.z, ps32 = (float)pscale;
-        bool defer = live & !small;
+        bool defer = EXACT ? false : (live & !small);
         for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
         // (a four-deep gather pipeline was measured: 50 us either way -- the loop is bound by the scalar loads of the view records and the
         // float64 projection of a wave with 2 waves per SIMD resident, not by the gather latency)
         unsigned nvalid = 0, pend_code = F3D_CODE_NONE;
         for (int v = 0; v < nviews; ++v) {
             const f3d_view& vw = views[v];                                        // wave-uniform: scalar loads
-            bool maybe, sure;
-            cull_point32(load_cull(vw), px32, py32, pz32, ps32, small, maybe, sure);
-            bool inside = live & small & sure;
-            if (live & small & maybe & !sure) {                                   // inside the float32 margin: decide with float64 FMAs
-                bool m64, s64;
-                cull_point64(vw, p, pscale, m64, s64);
-                inside = s64;
-                defer = defer | (m64 & !s64);                                     // within rounding of the plane itself
-            }
             bool hit = false;
             int iu = 0, iv = 0;
-            if (inside) {
-                bool unsure;
-                hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
-                defer = defer | unsure;
+            if (EXACT) {
+                if (live && f3d_inside_view(vw, p)) {
+                    double fu, fv;
+                    project_exact(vw, p, fu, fv);
+                    if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) { hit = true; iu = (int)fu; iv = (int)fv; }   // NaN compares false
+                }
+            } else {
+                bool maybe, sure;
+                cull_point32(load_cull(vw), px32, py32, pz32, ps32, small, maybe, sure);
+                bool inside = live & small & sure;
+                if (live & small & maybe & !sure) {                               // inside the float32 margin: decide with float64 FMAs
+                    bool m64, s64;
+                    cull_point64(vw, p, pscale, m64, s64);
+                    inside = s64;
+                    defer = defer | (m64 & !s64);                                 // within rounding of the plane itself
+                }
+                if (inside) {
+                    bool unsure;
+                    hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
+                    defer = defer | unsure;
+                }
             }
             vote_coded<true>(nvalid, hist + tid, pend_code);
             pend_code = (cmasks + (size_t)v * plane)[hit ? mask_offset<true>(iu, iv, wt) : none_off];
@@ -1156,7 +1167,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
         const bool trusted = finish_coded<WRITE_VOTES, true>(nvalid, hist + tid, words, lut, inv, nfilter, fcls, nclasses, threshold,
                                                              live & !defer, orig, classes, votes_out, bad);
         defer = defer | (live & !trusted);
-        if (defer) out_list[atomicAdd(out_count, 1u)] = src;
+        if (!EXACT && defer) out_list[atomicAdd(out_count, 1u)] = src;
         if (bad & !defer) atomicOr(err, F3D_DEVERR_FUSE);
     }
 }
@@ -1324,6 +1335,7 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes) {
 }
 
 size_t f3d_coded_masks_bytes(int nviews, int h, int w) { return (size_t)nviews * f3d_coded_plane(h, w); }
+extern "C" size_t f3d_coded_plane_bytes(int h, int w) { return (h > 0 && w > 0) ? f3d_coded_plane(h, w) : 0; }
 
 // which book: the filter's own labels when there are few of them (nothing else is ever looked at, voting.py:121-124);
 // otherwise the labels that occur in the masks
@@ -1454,6 +1466,15 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
         if ((e = raise_lds(km, lds_tier2)) != hipSuccess) return e;
         hipLaunchKernelGGL(km, dim3(1024), b, lds_tier2, s, (const T*)xyz, todo_count, todo, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
                            flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo2_count, todo2, cb);
+    }
+    if (fast && !masks) {                                    // only coded planes exist (f3d_fuse_chunk_coded_dev): reference arithmetic on them
+        if (V || nviews > 255) return hipErrorInvalidValue;
+        auto kx = k_fuse_mid<T, false, true>;
+        const size_t lds_tier3 = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
+        if ((e = raise_lds(kx, lds_tier3)) != hipSuccess) return e;
+        hipLaunchKernelGGL(kx, dim3(512), b, lds_tier3, s, (const T*)xyz, todo2_count, todo2, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
+                           flt.cls_dev, threshold, classes, (uint16_t*)nullptr, err, perm, gather_xyz ? 1 : 0, (unsigned int*)nullptr, (int32_t*)nullptr, cb);
+        return hipGetLastError();
     }
     if (mode == MODE_HIST8) {
         auto ke = k_fuse_exact<T, MODE_HIST8, V>;

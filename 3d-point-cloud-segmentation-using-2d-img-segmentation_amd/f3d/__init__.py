@@ -87,6 +87,9 @@ def library():
         'f3d_mask_presence_dev': (i32, [vp, vp, i32, i32, i32, vp, vp]),
         'f3d_fuse_chunked_begin_dev': (i32, [vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
         'f3d_fuse_chunk_dev': (i32, [vp, vp, i32, i64, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, dbl, vp, C.c_uint, vp, vp]),
+        'f3d_coded_plane_bytes': (C.c_size_t, [i32, i32]),
+        'f3d_code_planes_dev': (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        'f3d_fuse_chunk_coded_dev': (i32, [vp, vp, i32, i64, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, dbl, vp, C.c_uint, vp, vp]),
         'f3d_debug_fastpath_audit': (i32, [vp, vp, i32, i64, vp, i32, i32, i32, vp]),
         'f3d_debug_fuse_deferred': (i32, [vp, vp, vp]),
         'f3d_cloud_sort_cells_dev': (i32, [vp, vp, i32, i64, vp, vp, vp]),
@@ -605,6 +608,18 @@ class Context:
         f, nf = _filter(filter_classes)
         self._check(self._lib.f3d_fuse_chunk_dev(self._h, xyz_ptr, dtype, n, views_ptr, nviews, int(v_begin), int(v_end), masks_ptr, h, w,
                                                  int(nclasses), _ptr(f), nf, float(threshold), classes_ptr, int(flags), perm_ptr, stream))
+
+    def coded_plane_bytes(self, h, w):
+        return int(self._lib.f3d_coded_plane_bytes(int(h), int(w)))
+
+    def code_planes_dev(self, masks_ptr, nplanes, h, w, coded_ptr, stream=None):
+        self._check(self._lib.f3d_code_planes_dev(self._h, masks_ptr, int(nplanes), int(h), int(w), coded_ptr, stream))
+
+    def fuse_chunk_coded_dev(self, xyz_ptr, dtype, n, views_ptr, nviews, v_begin, v_end, coded_ptr, h, w, nclasses, threshold,
+                             filter_classes, classes_ptr, stream=None, flags=0, perm_ptr=None):
+        f, nf = _filter(filter_classes)
+        self._check(self._lib.f3d_fuse_chunk_coded_dev(self._h, xyz_ptr, dtype, n, views_ptr, nviews, int(v_begin), int(v_end), coded_ptr, h, w,
+                                                       int(nclasses), _ptr(f), nf, float(threshold), classes_ptr, int(flags), perm_ptr, stream))
 
     def rotate_dev(self, xyz_ptr, n, q_wxyz, out_ptr, stream=None):
         q = _f64(q_wxyz, (4,))

@@ -119,6 +119,19 @@ class HipChunkEngine:
                                 masks.data_ptr(), self.h, self.w, self.nclasses, self.threshold, self.flt, self.classes.data_ptr(),
                                 self._stream(), flags=self.flags, perm_ptr=self.perm_ptr)
 
+    # the coded exchange: this rank codes its own planes (the book of begin() is the same on every rank), coded planes travel
+    def coded_plane_bytes(self):
+        return self.ctx.coded_plane_bytes(self.h, self.w)
+
+    def code(self, masks, out):
+        """masks uint8 [k, H, W] -> out uint8 [k, coded_plane_bytes] (enqueue only)."""
+        self.ctx.code_planes_dev(masks.data_ptr(), masks.shape[0], self.h, self.w, out.data_ptr(), self._stream())
+
+    def chunk_coded(self, v_begin, v_end, coded):
+        self.ctx.fuse_chunk_coded_dev(self.xyz.data_ptr(), self.dtype, self.n, self.views.data_ptr(), len(self.views), v_begin, v_end,
+                                      coded.data_ptr(), self.h, self.w, self.nclasses, self.threshold, self.flt, self.classes.data_ptr(),
+                                      self._stream(), flags=self.flags, perm_ptr=self.perm_ptr)
+
 
 def overlapped_labels(dist, engine, mask_shard, gathered, nchunks):
     """One N-rank step with the exchange overlapped INSIDE the step.
@@ -156,3 +169,43 @@ def overlapped_labels(dist, engine, mask_shard, gathered, nchunks):
     for c in range(nchunks):
         works[c].wait()
         engine.chunk(c * world * vc, (c + 1) * world * vc, gathered)
+
+
+def overlapped_labels_coded(dist, engine, mask_shard, gathered_coded, nchunks):
+    """`overlapped_labels` with the mask CODING sharded as well: every rank codes only its own V / world masks and the ranks
+    all-gather coded planes (3 % more bytes on the wire, 1 / world of the coding work per rank, and no rank ever holds
+    a raw mask of another rank -- the engine's last tier works on codes).
+
+    gathered_coded: uint8 [V, engine.coded_plane_bytes()] buffer, planes in `chunk_layout` order.
+    1. labels present locally, all-reduced (MAX) -> the same code book on every rank (engine.begin);
+    2. per chunk: code the local slice, enqueue its all-gather (asynchronous; the coding of slice c+1 overlaps the transfer of c);
+    3. as soon as chunk c has landed the local points vote on it (engine.chunk_coded)."""
+    import torch
+    world = dist.get_world_size()
+    per = mask_shard.shape[0]
+    if per % nchunks:
+        raise ValueError(f'{per} masks per rank do not split into {nchunks} chunks')
+    vc = per // nchunks
+    plane = engine.coded_plane_bytes()
+    present = engine.presence(mask_shard)
+    if present is not None:
+        pres32 = present.to(torch.int32)                            # gloo has no MAX for uint8
+        dist.all_reduce(pres32, op=dist.ReduceOp.MAX)
+        present.copy_(pres32.to(torch.uint8))
+    engine.begin(present)
+    mine = torch.empty((per, plane), dtype=torch.uint8, device=mask_shard.device)
+    flat = gathered_coded.view(-1)
+    works = []
+    for c in range(nchunks):
+        engine.code(mask_shard[c * vc:(c + 1) * vc], mine[c * vc:(c + 1) * vc])
+        if mask_shard.is_cuda and dist.get_backend() != 'nccl':
+            torch.cuda.current_stream(mask_shard.device).synchronize()   # a host-side backend reads the buffer: the coding must have finished
+        out = flat[c * world * vc * plane:(c + 1) * world * vc * plane]
+        src = mine[c * vc:(c + 1) * vc].view(-1)
+        try:
+            works.append(dist.all_gather_into_tensor(out, src, async_op=True))
+        except (RuntimeError, NotImplementedError):                 # a backend without the flat form
+            works.append(dist.all_gather(list(out.view(world, -1).unbind(0)), src, async_op=True))
+    for c in range(nchunks):
+        works[c].wait()
+        engine.chunk_coded(c * world * vc, (c + 1) * world * vc, gathered_coded)

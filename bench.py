@@ -41,9 +41,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--points', type=int, default=10_000_000, help='points of the cloud (C3/C4: 10M), sharded over the ranks; per rank with --weak')
     ap.add_argument('--weak', action='store_true', help='N > 1: every rank owns --points points of an N x larger cloud (weak scaling)')
-    ap.add_argument('--exchange', default='pipelined', choices=['pipelined', 'chunked'],
+    ap.add_argument('--exchange', default='pipelined', choices=['pipelined', 'chunked', 'coded'],
                     help='N > 1: pipelined = the all-gather of step i+1 overlaps the kernels of step i (double-buffered masks); chunked = inside '
-                         'one step, the all-gather split into --chunks view chunks, chunk c+1 on the wire while chunk c votes')
+                         'one step, the all-gather split into --chunks view chunks, chunk c+1 on the wire while chunk c votes; coded = chunked with the '
+                         'mask coding sharded as well: every rank codes its own V/N masks, CODED planes are all-gathered')
     ap.add_argument('--chunks', type=int, default=2, help='view chunks per rank of --exchange chunked')
     ap.add_argument('--no-merge', action='store_true', help='skip the C5 bbox-merge leg (50M points, 4096 instances)')
     ap.add_argument('--views', type=int, default=64)
@@ -437,7 +438,8 @@ def main():
         out = mask_buf[i % 2]
         pending[i] = dist.all_gather_into_tensor(out.view(-1), masks_shard.view(-1), async_op=True)
 
-    chunked = use_dist and args.exchange == 'chunked'
+    chunked = use_dist and args.exchange in ('chunked', 'coded')
+    coded_x = use_dist and args.exchange == 'coded'
     if chunked:
         if overlap or args.prepared:
             raise SystemExit('--exchange chunked takes the caller-order cloud (the sort is part of the first chunk)')
@@ -445,10 +447,15 @@ def main():
         views_chunked = torch.from_numpy(np.ascontiguousarray(views_np[order])).to(dev)
         engine = sharding.HipChunkEngine(ctx, xyz, dtype, n, views_chunked, S, S, 133, 0.5, flt, classes, flags=flags)
         views = views_chunked                    # the gather buffer holds the planes in this order: one-shot calls on it use the same
+        if coded_x:
+            coded_buf = torch.empty((V, engine.coded_plane_bytes()), dtype=torch.uint8, device=dev)
 
     def step():
         if not use_dist:
             fuse()
+            return
+        if coded_x:                              # coded planes travel; no rank holds another rank's raw masks
+            sharding.overlapped_labels_coded(dist, engine, masks_shard, coded_buf, args.chunks)
             return
         if chunked:                              # masks_full is the gather buffer, planes in chunk order
             sharding.overlapped_labels(dist, engine, masks_shard, masks_full, args.chunks)
@@ -484,6 +491,11 @@ def main():
     chunk_check = None
     if chunked:                                             # the chunked step against one call over all views, same inputs
         stepped = classes.clone()
+        if coded_x:                                         # (the raw planes of the other ranks, for this check only, in the buffer's order)
+            for c in range(args.chunks):
+                vcn = V // world // args.chunks
+                part = masks_full.view(args.chunks, world, vcn, S, S)[c]
+                dist.all_gather_into_tensor(part.reshape(-1), masks_shard[c * vcn:(c + 1) * vcn].contiguous().view(-1))
         fuse(masks_full)
         stream.synchronize()
         chunk_check = bool(torch.equal(stepped, classes))
@@ -551,7 +563,7 @@ def main():
                                                   note='block64 = the 8-label alphabet of SURVEY 8(d): the small-alphabet (dword-bin) instance, the fastest '
                                                        'of the four; `variants` has iid / 40 / 100 labels and the filter list through the same step'),
                                exchange='none' if not use_dist else (f'RCCL all_gather of {V // world} masks/rank per step, double-buffered and overlapped with the previous step' if not chunked else
-                                                                     f'RCCL all_reduce(MAX) of the label-presence bytes + {args.chunks} all_gathers of {V // world // args.chunks} masks/rank per step; chunk c+1 on the wire while chunk c votes (vote state carried in HBM)')),
+                                                                     f'RCCL all_reduce(MAX) of the label-presence bytes + {args.chunks} all_gathers of {V // world // args.chunks} {"CODED " if coded_x else ""}masks/rank per step; chunk c+1 on the wire while chunk c votes (vote state carried in HBM)' + (' -- each rank codes only its own masks' if coded_x else ''))),
                    roofline=roofline)
 
     # secondary, HBM-streaming kernels of the same path (not part of `value`)

@@ -224,6 +224,19 @@ int f3d_fuse_chunk_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n
                        int v_begin, int v_end, const uint8_t* masks /*[nviews,H,W]*/, int h, int w, int nclasses,
                        const int32_t* filter /*host*/, int nfilter, double threshold, int64_t* classes,
                        unsigned flags, const int32_t* perm, void* stream);
+/* The same with the mask CODING sharded as well: a rank codes only the masks it produced -- with the book of
+ * f3d_fuse_chunked_begin_dev, identical on every rank -- and the ranks all-gather CODED planes (f3d_coded_plane_bytes(h, w) each:
+ * 8 x 8-pixel tiles of vote-bin codes with a one-tile border; ~3 % more bytes than the raw plane).
+ *   f3d_code_planes_dev        `nplanes` raw masks -> `coded` (nplanes x f3d_coded_plane_bytes, 8-byte aligned), enqueue only.
+ *   f3d_fuse_chunk_coded_dev   like f3d_fuse_chunk_dev, but `coded` = the gather buffer of coded planes, [nviews] planes in the
+ *                              order of views_dev, read where they lie.  No raw mask ever reaches this rank, so the last
+ *                              tier runs the reference's arithmetic on the coded planes. */
+size_t f3d_coded_plane_bytes(int h, int w);
+int f3d_code_planes_dev(f3d_ctx* ctx, const uint8_t* masks, int nplanes, int h, int w, uint8_t* coded, void* stream);
+int f3d_fuse_chunk_coded_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n, const f3d_view* views_dev, int nviews,
+                             int v_begin, int v_end, const uint8_t* coded /*[nviews] coded planes*/, int h, int w,
+                             int nclasses, const int32_t* filter /*host*/, int nfilter, double threshold, int64_t* classes,
+                             unsigned flags, const int32_t* perm, void* stream);
 /* Test hook: cell-sorts the cloud and evaluates, for every (point, view) pair, the accelerated decisions of the
  * fused kernel (wave-box and per-point float32 culls, centre + offset projection for a w x h image) next to the exact
  * arithmetic.  stats[0] = pairs inside the frustum, stats[1] = pairs the offset projection leaves to the exact

@@ -172,6 +172,61 @@ def test_two_ranks_label_their_shards_with_the_hip_path(tmp_path):
     assert np.array_equal(single, want) and (want != 133).mean() > 0.5
 
 
+def _rank_overlap_coded(rank, world, port, n, nchunks, out_dir):
+    """One rank of the step with the CODED exchange: the rank codes its own masks, coded planes are all-gathered (gloo) chunk by
+    chunk, f3d_fuse_chunk_coded_dev votes on them; this rank never sees a raw mask of the other rank."""
+    import torch
+    import torch.distributed as dist
+    from f3d import sharding
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', 0)
+    sc = synth.scene('C1', n=n)
+    V = 16
+    q, t = synth.ring_views(V)
+    masks = synth.masks(V, sc['h'], sc['w'], 'block64x40')
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], q, t, sc['max_depth'])
+    vc, order = sharding.chunk_layout(V, world, nchunks)
+    v0, v1 = sharding.view_bounds(V, rank, world)
+    lo, hi = sharding.point_bounds(n, rank, world)
+    pts = sc['points'][lo:hi].copy()
+    pts[::53] *= 1e31                                               # deferred in every tier: labelled by the reference arithmetic on coded planes
+    x = torch.from_numpy(pts).to(dev)
+    cls = torch.empty(hi - lo, dtype=torch.int64, device=dev)
+    ctx = f3d.Context(0)
+    eng = sharding.HipChunkEngine(ctx, x, f3d.F64, hi - lo, torch.from_numpy(views[order]).to(dev), sc['h'], sc['w'], 133, 0.0, None, cls,
+                                  flags=f3d.FUSE_SORT)
+    shard = torch.from_numpy(masks[v0:v1].copy()).to(dev)
+    gathered = torch.empty((V, eng.coded_plane_bytes()), dtype=torch.uint8, device=dev)
+    sharding.overlapped_labels_coded(dist, eng, shard, gathered, nchunks)
+    ctx.take_device_error(torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    labels = sharding.gather_labels(dist, cls.cpu(), n)
+    np.save(os.path.join(out_dir, f'coded{rank}.npy'), labels.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_coded_masks(tmp_path):
+    """SURVEY 8(e1) / DESIGN section 5: mask coding sharded by view, coded all-gather, exact tier on coded planes -- labels equal
+    the oracle's on the whole cloud."""
+    import torch.multiprocessing as mp
+    n, V = 30_001, 16
+    mp.spawn(_rank_overlap_coded, args=(2, _free_port(), n, 2, str(tmp_path)), nprocs=2, join=True)
+    sc = synth.scene('C1', n=n)
+    q, t = synth.ring_views(V)
+    masks = synth.masks(V, sc['h'], sc['w'], 'block64x40')
+    pts = sc['points'].copy()
+    for r in range(2):
+        lo, hi = n * r // 2, n * (r + 1) // 2
+        pts[lo:hi][::53] *= 1e31
+    with np.errstate(all='ignore'):
+        want = O.project_vote_argmax(pts, sc['K'], q, t, masks, sc['max_depth'], 133, 0.0, None)
+    assert (want != 133).mean() > 0.3
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f'coded{r}.npy'), want), r
+
+
 def _rank_overlap(rank, world, port, n, nchunks, out_dir):
     """One rank of the step with the exchange overlapped inside it: chunked all-gather (gloo, host tensors copied to device
     0 as they land) + f3d's view-chunked fused call on this rank's point range."""

@@ -554,8 +554,9 @@ def test_nclasses_edge_values(ctx):
 
 
 # ---- the view-chunked call (f3d_fuse_chunked_begin_dev / f3d_fuse_chunk_dev): same labels as the one-shot call ----------------
-def _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, flags, bounds, f32=False, nclasses=133, order=None, presence='own'):
-    """bounds: chunk boundaries [0, ..., V].  order: views (and masks) handed over in this order (a permutation of range(V))."""
+def _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, flags, bounds, f32=False, nclasses=133, order=None, presence='own', coded=False):
+    """bounds: chunk boundaries [0, ..., V].  order: views (and masks) handed over in this order (a permutation of range(V)).
+    coded: the planes are coded up front with f3d_code_planes_dev (as another rank would) and handed over coded."""
     import torch
     dev = torch.device('cuda', 0)
     if order is not None:
@@ -572,12 +573,23 @@ def _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, flags, bounds, f32=False
         if presence == 'own':
             ctx.mask_presence_dev(md.data_ptr(), V, H, W, present.data_ptr(), s.cuda_stream)
         ctx.fuse_chunked_begin_dev(present.data_ptr() if presence == 'own' else None, n, V, H, W, nclasses, flt, s.cuda_stream)
+        if coded:
+            cd = torch.full((V, ctx.coded_plane_bytes(H, W)), 0xEE, dtype=torch.uint8, device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            for a, b in zip(bounds[:-1], bounds[1:]):                                   # coded chunk by chunk, like the ranks do
+                ctx.code_planes_dev(md[a:b].data_ptr(), b - a, H, W, cd[a:b].data_ptr(), s.cuda_stream)
+            md.fill_(0xEE)                                                              # the raw masks are gone: nothing may read them
+            s.wait_stream(torch.cuda.current_stream(dev))
         for a, b in zip(bounds[:-1], bounds[1:]):
-            ctx.fuse_chunk_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, a, b, md.data_ptr(), H, W, nclasses, thr, flt, cls.data_ptr(),
-                               s.cuda_stream, flags=flags)
+            if coded:
+                ctx.fuse_chunk_coded_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, a, b, cd.data_ptr(), H, W, nclasses, thr, flt, cls.data_ptr(),
+                                         s.cuda_stream, flags=flags)
+            else:
+                ctx.fuse_chunk_dev(x.data_ptr(), dt, n, vd.data_ptr(), V, a, b, md.data_ptr(), H, W, nclasses, thr, flt, cls.data_ptr(),
+                                   s.cuda_stream, flags=flags)
         ctx.take_device_error(s.cuda_stream)
         s.synchronize()
-    if presence == 'own':
+    if presence == 'own' and not coded:
         got = np.flatnonzero(present.cpu().numpy())
         assert np.array_equal(got, np.unique(masks)), 'labels present'
     return cls.cpu().numpy()
@@ -610,6 +622,10 @@ def test_view_chunked_call_equals_the_one_shot_call(ctx, mask_kind):
                                                (list(range(V + 1)), None, f3d.FUSE_SORT, 'all')]:
             got = _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, flags, bounds, f32=f32, order=order, presence=presence)
             assert np.array_equal(got, one), (mask_kind, thr, flt, f32, bounds)
+        # the coded exchange (f3d_code_planes_dev + f3d_fuse_chunk_coded_dev): the raw masks are destroyed before the first chunk votes
+        for bounds, order, presence in [([0, 8, 16, V], None, 'own'), ([0, V], rng.permutation(V), 'all'), ([0, 5, V], None, 'own')]:
+            got = _dev_fuse_chunked(ctx, pts, views, masks, flt, thr, f3d.FUSE_SORT, bounds, f32=f32, order=order, presence=presence, coded=True)
+            assert np.array_equal(got, one), ('coded', mask_kind, thr, flt, f32, bounds)
 
 
 def test_view_chunked_call_deferred_points_errors_and_sequence(ctx):
@@ -625,10 +641,18 @@ def test_view_chunked_call_deferred_points_errors_and_sequence(ctx):
     got = _dev_fuse_chunked(ctx, pts, views, sc['masks'], None, 0.0, f3d.FUSE_SORT, [0, 1, 3, V])
     assert np.array_equal(got, one)
     assert ctx.fuse_deferred()[0] >= len(pts[::97])
+    # the same through the coded exchange: the deferred points end in the reference-arithmetic tier that reads CODED planes
+    got = _dev_fuse_chunked(ctx, pts, views, sc['masks'], None, 0.0, f3d.FUSE_SORT, [0, 1, 3, V], coded=True)
+    assert np.array_equal(got, one) and ctx.fuse_deferred()[1] >= len(pts[::97])
+    want = O.project_vote_argmax(sc['points'][:3000], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.0, None)
+    huge = sc['points'][:3000] * 1.0
+    assert np.array_equal(_dev_fuse_chunked(ctx, huge, views, sc['masks'], None, 0.0, 0, [0, 2, V], coded=True), want)
     # a rejected label in a middle chunk: IndexError once the call is complete, like the one-shot call
     bad = sc['masks'].copy(); bad[1, 100:300, 100:300] = 200
     with pytest.raises(IndexError, match='project_vote_argmax'):
         _dev_fuse_chunked(ctx, sc['points'], views, bad, None, 0.0, 0, [0, 1, 2, V])
+    with pytest.raises(IndexError, match='project_vote_argmax'):
+        _dev_fuse_chunked(ctx, sc['points'], views, bad, None, 0.0, 0, [0, 1, 2, V], coded=True)
     # chunks out of sequence, a chunk without begin, more than 255 views
     x = torch.from_numpy(sc['points']).to(dev); vd = torch.from_numpy(views).to(dev); md = torch.from_numpy(sc['masks']).to(dev)
     cls = torch.empty(len(pts), dtype=torch.int64, device=dev)

@@ -88,6 +88,61 @@ class OracleChunkEngine:
             self.labels = O.segment(self.votes, 133, self.thr, self.flt)
 
 
+class OracleCodedEngine(OracleChunkEngine):
+    """The coded exchange on CPU: "coding" = the raw plane behind an 8-byte header that names the book (so that a plane coded
+    before begin(), or with another rank's book, is noticed), padded like the real coded planes are larger than raw ones."""
+
+    def coded_plane_bytes(self):
+        return self.sc['masks'][0].size + 24
+
+    def code(self, masks, out):
+        assert self.present is not None, 'coding needs the book of begin()'
+        k = masks.shape[0]
+        out[:, :8] = torch.from_numpy(np.frombuffer(np.int64(self.present.sum()).tobytes(), np.uint8).copy())
+        out[:, 8:8 + masks[0].numel()] = masks.reshape(k, -1)
+        out[:, 8 + masks[0].numel():] = 0
+
+    def chunk_coded(self, v_begin, v_end, gathered):
+        g = gathered.numpy()
+        assert (np.frombuffer(g[v_begin:v_end, :8].tobytes(), np.int64) == self.present.sum()).all()
+        hw = self.sc['masks'][0].size
+        planes = torch.from_numpy(g[:, 8:8 + hw].reshape((len(g),) + self.sc['masks'].shape[1:]).copy())
+        self.chunk(v_begin, v_end, planes)
+
+
+def _overlap_coded_worker(rank, world, port, n, nchunks, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        sc = _ring_scene(n)
+        V = len(sc['masks'])
+        v0, v1 = sharding.view_bounds(V, rank, world)
+        shard = torch.from_numpy(sc['masks'][v0:v1].copy())
+        vc, order = sharding.chunk_layout(V, world, nchunks)
+        lo, hi = sharding.point_bounds(n, rank, world)
+        eng = OracleCodedEngine(sc['points'][lo:hi], sc, order, 0.0, None)
+        gathered = torch.full((V, eng.coded_plane_bytes()), 255, dtype=torch.uint8)
+        sharding.overlapped_labels_coded(dist, eng, shard, gathered, nchunks)
+        assert eng.seen == [(c * world * vc, (c + 1) * world * vc) for c in range(nchunks)]
+        assert np.array_equal(np.flatnonzero(eng.present), np.unique(sc['masks']))     # the union over BOTH ranks' masks
+        labels = sharding.gather_labels(dist, torch.from_numpy(eng.labels), n)
+        np.save(os.path.join(out_dir, f'coded_{rank}.npy'), labels.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nchunks', [1, 2])
+def test_two_rank_coded_exchange_equals_single_process(tmp_path, nchunks):
+    """overlapped_labels_coded on CPU (gloo, world 2): the book is agreed before any plane is coded, each rank codes only its own
+    planes, the coded planes land in chunk order, labels equal the single-process oracle."""
+    n, world = 2001, 2
+    mp.spawn(_overlap_coded_worker, args=(world, _free_port(), n, nchunks, str(tmp_path)), nprocs=world, join=True)
+    sc = _ring_scene(n)
+    want = O.project_vote_argmax(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'], 133, 0.0, None)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f'coded_{r}.npy'), want)
+
+
 def _overlap_worker(rank, world, port, n, nchunks, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
