@@ -681,6 +681,9 @@ __device__ __forceinline__ void wave_box(float& lo0, float& hi0, float& lo1, flo
 // F3D_BIN32_MAX_CODES codes, otherwise 8-bit bins packed 4 per dword.  The launcher enqueues one instance of each kind; an
 // instance returns at once unless the code book's size is in its range [cmin, cmax].
 // ------------------------------------------------------------------------------------------
+#ifndef F3D_XCD_CHUNK_LOG2
+#define F3D_XCD_CHUNK_LOG2 6             // 64 tiles per chunk of the XCD-aware tile mapping (64 .. 256 measured alike)
+#endif
 #ifndef F3D_FUSE_WAVES
 #define F3D_FUSE_WAVES 3                 // waves per SIMD the register allocation of k_fuse must allow (4 spills: measured slower)
 #endif
@@ -769,16 +772,22 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     if (TLDS && ngroups == 1) stage_group(0);
     __syncthreads();
 
-    // XCD-aware tile mapping: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so XCD x walks the
-    // contiguous tile range [x*q, (x+1)*q): with a cell-sorted cloud that is one compact region of space, whose pixels
-    // in every mask stay resident in that XCD's 4 MiB L2.  Placement affects speed only, never results.
-    const int tiles_per_xcd = (ntiles + 7) / 8;
+    // XCD-aware tile mapping: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch).  The XCDs take CHUNKS of
+    // 64 consecutive tiles in turn (chunk c -> XCD c mod 8): with a cell-sorted cloud a chunk is a compact region of
+    // space whose pixels in every mask stay resident in that XCD's 4 MiB L2, and the chunks deal the cloud's cheap and expensive
+    // regions (points seen by few / by many views) evenly.  r1/r2 gave every XCD ONE contiguous eighth of the cloud: the XCD
+    // with the busiest region finished last while others idled -- 0.98 -> 0.85 ms for the fused call at C3, 1.46 -> 1.23 ms with
+    // iid masks (profiles/r03_summary.md).  Placement affects speed only, never results.
+    int xlog = F3D_XCD_CHUNK_LOG2;                                        // chunk = 2^xlog tiles, smaller for small clouds: at least four chunks per XCD
+    while (xlog > 0 && ntiles < (32 << xlog)) --xlog;
+    const int chunk_rows = (ntiles + (8 << xlog) - 1) >> (xlog + 3);
+    const int tiles_per_xcd = chunk_rows << xlog;                         // positions j of one XCD's list (the last row may hold fewer tiles)
     const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = gridDim.x >> 3;
     uint32_t* const hcol0 = hist + tid;
     uint32_t* const hcol1 = PPL == 2 ? hist + hdw * F3D_BLOCK + tid : hcol0;
     for (int j = bx; j < tiles_per_xcd; j += gx) {
-        const int tile = xcd * tiles_per_xcd + j;
-        if (tile >= ntiles) break;
+        const int tile = ((j >> xlog) << (xlog + 3)) + (xcd << xlog) + (j & ((1 << xlog) - 1));
+        if (tile >= ntiles) continue;
         const int i0 = tile * TILE + (tid >> 6) * (64 * PPL) + lane;      // this lane's first point; its second is i0 + 64
         bool live[2], act[2], defer[2];
         int orig[2];

@@ -108,6 +108,33 @@ __device__ __forceinline__ void grid_from_partials(const bbox6* __restrict__ par
     }
 }
 
+// the bits of axis c's cell index `i` at their places in the key (a Morton code with per-axis bit counts: from the most significant
+// level down, every axis that still has a bit at that level contributes it)
+__device__ __forceinline__ uint32_t spread_axis(uint32_t i, int c, const int bits[3]) {
+    uint32_t key = 0;
+    int pos = F3D_SORT_KEY_BITS;                                    // next output position, counted down
+    for (int level = F3D_SORT_KEY_BITS - 1; level >= 0; --level)
+        for (int a = 0; a < 3; ++a)
+            if (bits[a] > level) { --pos; if (a == c) key |= ((i >> level) & 1u) << pos; }
+    return key;
+}
+
+constexpr int RS_LUT = 1024;                 // per-axis spread tables in LDS when no axis has more cells than this (the usual case: 64 x 64 x 16)
+
+// float32 is enough for the cell of a point: the ORDER of the points never changes a result, only how compact a wave's 128 points are
+template <typename T>
+__device__ __forceinline__ void cell_index(const T* __restrict__ p, const float lo[3], const float inv[3], const int dim[3], int idx[3], bool& ok) {
+    ok = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float x = (float)p[c];
+        ok = ok && (fabsf(x) < 1e30f);
+        int k = (int)((x - lo[c]) * inv[c]);
+        k = k < 0 ? 0 : (k >= dim[c] ? dim[c] - 1 : k);
+        idx[c] = k;
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ uint32_t cell_of(const T* __restrict__ p, const f3d_cellgrid& g) {
     int idx[3];
@@ -130,9 +157,15 @@ __device__ __forceinline__ uint32_t cell_of(const T* __restrict__ p, const f3d_c
 }
 
 // ---- the radix passes --------------------------------------------------------------------------------------------
-constexpr int RS_THREADS = 512;              // 8 waves per block
+#ifndef F3D_RS_THREADS
+#define F3D_RS_THREADS 512
+#endif
+#ifndef F3D_RS_ROUNDS
+#define F3D_RS_ROUNDS 16
+#endif
+constexpr int RS_THREADS = F3D_RS_THREADS;   // 8 waves per block
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ROUNDS = 16;                // a wave walks 16 x 64 consecutive keys
+constexpr int RS_ROUNDS = F3D_RS_ROUNDS;     // a wave walks 16 x 64 consecutive keys
 constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;   // 8192 keys per block
 
 // item (wave w, round r, lane l) of tile b: consecutive lanes = consecutive keys (coalesced), consecutive rounds and waves
@@ -147,6 +180,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_keys(const T* __restrict__ xy
                                                          sort_key_t* __restrict__ keys, uint32_t* __restrict__ blkhist, int ntiles) {
     __shared__ uint32_t hist[256];
     __shared__ f3d_cellgrid sg;
+    __shared__ uint16_t lut[3][RS_LUT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) grid_from_partials(partial, nparts, &sg);
     if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
@@ -157,11 +191,26 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_keys(const T* __restrict__ xy
         g.dim[c] = __builtin_amdgcn_readfirstlane(g.dim[c]);
         g.bits[c] = __builtin_amdgcn_readfirstlane(g.bits[c]);
     }
-#pragma unroll 4
+    const bool tables = g.dim[0] <= RS_LUT && g.dim[1] <= RS_LUT && g.dim[2] <= RS_LUT;
+    if (tables) {                                                   // key = lut[0][ix] | lut[1][iy] | lut[2][iz]: three LDS reads instead of a 48-step bit loop
+        for (int c = 0; c < 3; ++c)
+            for (int i = threadIdx.x; i < g.dim[c]; i += RS_THREADS) lut[c][i] = (uint16_t)spread_axis((uint32_t)i, c, g.bits);
+        __syncthreads();
+    }
+    const float lo[3] = {(float)g.lo[0], (float)g.lo[1], (float)g.lo[2]};
+    const float inv[3] = {(float)g.inv_cell[0], (float)g.inv_cell[1], (float)g.inv_cell[2]};
+#pragma unroll 8
     for (int r = 0; r < RS_ROUNDS; ++r) {
         const int64_t i = rs_item(blockIdx.x, wave, r, lane);
         if (i < n) {
-            const uint32_t key = cell_of(xyz + 3 * i, g);
+            uint32_t key;
+            if (tables) {
+                int idx[3]; bool ok;
+                cell_index(xyz + 3 * i, lo, inv, g.dim, idx, ok);
+                key = ok ? ((uint32_t)lut[0][idx[0]] | lut[1][idx[1]] | lut[2][idx[2]]) : ((1u << F3D_SORT_KEY_BITS) - 1u);
+            } else {
+                key = cell_of(xyz + 3 * i, g);
+            }
             keys[i] = (sort_key_t)key;
             atomicAdd(&hist[key & 0xFFu], 1u);
         }

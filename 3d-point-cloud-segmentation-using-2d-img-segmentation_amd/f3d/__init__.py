@@ -39,7 +39,10 @@ _lib = None
 
 
 def library_path():
-    return Path(__file__).resolve().parent / 'libf3d_hip.so'
+    """The in-tree build.  F3D_LIBRARY names another build of the same library (the A/B timing scripts under scripts/ point the
+    loader at a variant this way instead of overwriting the product's file)."""
+    alt = os.environ.get('F3D_LIBRARY')
+    return Path(alt).resolve() if alt else Path(__file__).resolve().parent / 'libf3d_hip.so'
 
 
 def library():
