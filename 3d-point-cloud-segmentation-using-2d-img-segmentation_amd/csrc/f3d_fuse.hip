@@ -681,6 +681,9 @@ __device__ __forceinline__ void wave_box(float& lo0, float& hi0, float& lo1, flo
 // F3D_BIN32_MAX_CODES codes, otherwise 8-bit bins packed 4 per dword.  The launcher enqueues one instance of each kind; an
 // instance returns at once unless the code book's size is in its range [cmin, cmax].
 // ------------------------------------------------------------------------------------------
+#ifndef F3D_VTAB_GLOBAL
+#define F3D_VTAB_GLOBAL 0                // 1: M, t, mnorm of the views always from the transposed global table (7.7 KB less LDS per block)
+#endif
 #ifndef F3D_XCD_CHUNK_LOG2
 #define F3D_XCD_CHUNK_LOG2 6             // 64 tiles per chunk of the XCD-aware tile mapping (64 .. 256 measured alike)
 #endif
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     float* ctab = reinterpret_cast<float*>(lds_u32);                      // [64][F3D_CULL_ROW] cull planes (+ image size) of one view group
     uint32_t* lutw = TLDS ? lds_u32 + 64 * F3D_CULL_ROW : lds_u32;        // lut[256], inv[256] (bytes), cmin[256] (uint16): F3D_BOOK_DWORDS
     double* vtab = reinterpret_cast<double*>(lutw + F3D_BOOK_DWORDS);     // [F3D_VHEAD][64]: M, t, mnorm of the group's views
-    uint32_t* hist = TLDS ? lutw + F3D_BOOK_DWORDS + 2 * F3D_VHEAD * 64 : lutw + F3D_BOOK_DWORDS; // [PPL][hdw][F3D_BLOCK]
+    uint32_t* hist = (TLDS && !F3D_VTAB_GLOBAL) ? lutw + F3D_BOOK_DWORDS + 2 * F3D_VHEAD * 64 : lutw + F3D_BOOK_DWORDS; // [PPL][hdw][F3D_BLOCK]
     const uint16_t* vmin = (WRAP || nviews > 255) ? nullptr : reinterpret_cast<const uint16_t*>(lutw + 128);   // totals beyond 255: the division itself
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
     const uint8_t* inv = lut + 256;
@@ -764,12 +767,14 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             const int vi = k / 24, f = k - vi * 24;
             ctab[vi * F3D_CULL_ROW + f] = reinterpret_cast<const float*>(&views[64 * g + vi].cull_n32[0][0])[f];
         }
-        for (int k = tid; k < nv * F3D_VHEAD; k += F3D_BLOCK) {
-            const int vi = k / F3D_VHEAD, f = k - vi * F3D_VHEAD;
-            vtab[f * 64 + vi] = reinterpret_cast<const double*>(&views[64 * g + vi])[f];
-        }
+        if (!F3D_VTAB_GLOBAL)
+            for (int k = tid; k < nv * F3D_VHEAD; k += F3D_BLOCK) {
+                const int vi = k / F3D_VHEAD, f = k - vi * F3D_VHEAD;
+                vtab[f * 64 + vi] = reinterpret_cast<const double*>(&views[64 * g + vi])[f];
+            }
     };
-    if (TLDS && ngroups == 1) stage_group(0);
+    if (TLDS && ngroups > 1) return;                                      // (never launched: LDS-staged tables serve one 64-view group, see launch_fuse_t)
+    if (TLDS) stage_group(0);
     __syncthreads();
 
     // XCD-aware tile mapping: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch).  The XCDs take CHUNKS of
@@ -871,7 +876,6 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
         };
 
         for (int g = 0; g < ngroups; ++g) {
-            if (TLDS && ngroups > 1) { __syncthreads(); stage_group(g); __syncthreads(); }
             // lane j <-> view 64g + j: classify the wave's box against that view's planes, project the box centre
             const int vj = 64 * g + lane;
             bool box_out = false, box_in = true, own_image = false;
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             centre_row mine = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0, 0};
             bool row_ok = false;
             if (vj < nviews && !box_out && wave_any)
-                row_ok = centre_precompute(TLDS ? vtab + lane : vtabT + (size_t)g * F3D_VHEAD * 64 + lane, 64, c0, c1, c2, e0, e1, e2, umaxf, pitch, mine);
+                row_ok = centre_precompute((TLDS && !F3D_VTAB_GLOBAL) ? vtab + lane : vtabT + (size_t)g * F3D_VHEAD * 64 + lane, 64, c0, c1, c2, e0, e1, e2, umaxf, pitch, mine);
             mine.obase += (unsigned)vj * plane;             // absolute: the view's plane included
             const unsigned long long valid_m = __ballot(vj < nviews);
             unsigned long long out_m = __ballot(vj < nviews && box_out);
@@ -1324,7 +1328,7 @@ inline int grid_for(int64_t n, int per_block, int cap) {
 #endif
 
 static size_t fuse_lds_bytes(int hist_dwords_per_point, int ppl, bool tables = true) {   // k_fuse: [tables +] code book + histograms of `ppl` points per lane
-    return ((tables ? 64 * F3D_CULL_ROW + 2 * F3D_VHEAD * 64 : 0) + F3D_BOOK_DWORDS) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
+    return ((tables ? 64 * F3D_CULL_ROW + (F3D_VTAB_GLOBAL ? 0 : 2 * F3D_VHEAD * 64) : 0) + F3D_BOOK_DWORDS) * sizeof(uint32_t) + (size_t)hist_dwords_per_point * ppl * F3D_BLOCK * sizeof(uint32_t);
 }
 size_t f3d_fuse_carry_bytes(int64_t n, int nclasses) {     // packed bins of every point slot of the 256- or 512-point tiles
     const size_t words_max = (size_t)((nclasses + 1 + 2 + 3) >> 2);
@@ -1430,7 +1434,7 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
         return hipErrorInvalidValue;                         // 32-bit point indices and mask offsets; filter list in device memory
     const dim3 g(grid), b(F3D_BLOCK), ge(fast ? 512 : grid);
     const int words_max = (nclasses + 1 + 2 + 3) >> 2;      // every label 0..nclasses present, plus the codes "no sample" and "rejected"
-    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2), lds_full = fuse_lds_bytes(words_max, 2, false);
+    const size_t lds_small = fuse_lds_bytes(F3D_BIN32_MAX_CODES, 2, cnv <= 64), lds_full = fuse_lds_bytes(words_max, 2, false);
     float* ctabT = reinterpret_cast<float*>(tables);
     double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((cnv + 63) / 64) * 64 * 24 * sizeof(float));
     const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses);
@@ -1440,19 +1444,23 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
         // the guarded vote: an 8-bit bin of a real code can wrap (more than 255 views), or the "no sample" byte could (a point casts up to
         // nviews + 3 ngroups + 2 votes, placeholders included: from ~240 views on)
         const bool wrap = nviews + 3 * ((nviews + 63) / 64) + 2 > 255;
-        auto ks = k_fuse<T, 2, V, true, false, true, CARRY>;     // dword bins: at most F3D_BIN32_MAX_CODES codes
+        // the view tables of ONE 64-view group are staged in LDS; with more views every instance reads the transposed global copies (the
+        // tile loop then has no block-wide barrier, and the register allocation does not have to serve a path C3 never takes)
+        const bool one_group = cnv <= 64;
+        auto ks = one_group ? k_fuse<T, 2, V, true, false, true, CARRY> : k_fuse<T, 2, V, true, false, false, CARRY>;     // dword bins: at most F3D_BIN32_MAX_CODES codes
         // 8-bit bins, 4 per dword, 2 points per lane: <= 48 codes with the view tables in LDS; <= 100 codes / any alphabet with the tables in
         // global memory and 25 / all bin words per point (3 / 2 blocks per CU)
         auto km2 = k_fuse<T, 2, V, false, false, true, CARRY>;
         auto km3 = k_fuse<T, 2, V, false, false, false, CARRY>;
         auto kf = km3;                                           // any alphabet: the same code with room for every bin (2 blocks per CU)
         if (!CARRY && wrap) { km2 = k_fuse<T, 2, V, false, true, true, false>; km3 = kf = k_fuse<T, 2, V, false, true, false, false>; }
+        if (!one_group) km2 = km3;
         const size_t lds_large = fuse_lds_bytes(words_max < F3D_PACKED_LARGE_WORDS ? words_max : F3D_PACKED_LARGE_WORDS, 2, false);
         if ((e = raise_lds(ks, lds_small)) != hipSuccess || (e = raise_lds(kf, lds_full > lds_large ? lds_full : lds_large)) != hipSuccess) return e;
         // up to four instances are enqueued (dword bins for tiny alphabets; packed 8-bit bins for up to 48, up to 100 and for any number
         // of codes): LDS per block decides how many blocks a CU holds, and only the device
         // knows how many labels the masks contain -- the code book says which instance runs, the others return at once
-        const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2);
+        const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2, one_group);
         hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
                            classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
         if (nclasses + 3 > F3D_BIN32_MAX_CODES)
