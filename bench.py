@@ -521,8 +521,9 @@ def main():
     traffic, traffic_src = None, 'no PMC pass of this build under profiles/ (the CSV names another libf3d_hip.so)'
     import hashlib
     lib_sha = hashlib.sha256(f3d.library_path().read_bytes()).hexdigest()[:16]
-    pmc = ROOT / 'profiles' / 'r02_pmc_by_kernel.csv'
-    if pmc.is_file() and n == 10_000_000 and V == 64 and S == 1024 and not args.f32 and world == 1:
+    pmc = ROOT / 'profiles' / 'r03_pmc_by_kernel.csv'
+    if (pmc.is_file() and n == 10_000_000 and V == 64 and S == 1024 and not args.f32 and world == 1 and args.masks == 'block64' and
+            not (args.prepared or args.sorted or args.no_sort or args.filter)):      # the counters were taken on the default workload only
         lines = pmc.read_text().splitlines()
         if lines and lines[0].strip() == f'# lib_sha16={lib_sha}':
             vals = {}
@@ -532,7 +533,7 @@ def main():
                     vals[parts[1]] = float(parts[2])
             if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
                 traffic = int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
-                traffic_src = (f'profiles/r02_pmc_by_kernel.csv (lib {lib_sha}): (FETCH_SIZE + WRITE_SIZE) KB per k_fuse launch, raw (the x2 '
+                traffic_src = (f'profiles/r03_pmc_by_kernel.csv (lib {lib_sha}): (FETCH_SIZE + WRITE_SIZE) KB per k_fuse launch, raw (the x2 '
                                'FETCH_SIZE correction is calibrated for wide streams, not for 1-byte gathers; L2 misses incl. Infinity-Cache hits)')
     roofline = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
