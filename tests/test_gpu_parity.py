@@ -702,7 +702,8 @@ def test_rotate_dev_equals_host_pointer_rotate(ctx):
 
 def test_vote_segment_merge_randomised_configurations(ctx):
     """scripts/aux_fuzz.py: batched vote (offending frames, negative and duplicate lookups), segment_votes (thresholds, filter lists) and
-    merge_bb (random blob scenes with and without the inner-hull prefilter) against the oracle."""
+    merge_bb (random blob scenes; the oracle's fit injected with and without the candidate prefilter, or the product's own GPU fit) against the
+    oracle; f3d_obb_fit on random, lattice and nearly flat point sets."""
     import contextlib
     import importlib.util
     import io
@@ -713,6 +714,8 @@ def test_vote_segment_merge_randomised_configurations(ctx):
     rng = np.random.default_rng(31)
     for k in range(60):
         fuzz.vote_config(ctx, rng)
+        if k % 3 == 0:
+            fuzz.obb_config(ctx, rng)                           # f3d_obb_fit: hull vertices against scipy's Qhull, boxes against the oracle's recipe
         if k % 6 == 0:
             with contextlib.redirect_stdout(io.StringIO()):
                 fuzz.merge_config(rng)

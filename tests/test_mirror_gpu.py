@@ -395,13 +395,24 @@ def _same_boxes(got_info, want_info, tol=1e-8):
 
 
 def test_merge_bb_own_gpu_fit_end_to_end_against_the_oracle():
-    """The product's OWN fit (f3d_obb_candidates_dev + f3d_obb_fit_dev, no box_fn) end to end against the oracle's literal restatement
-    of merge_bb with its scipy / LAPACK fit: same ids, areas and entries; boxes equal as corner sets within 1e-8 (the hull vertex
-    sets are identical, the eigen-solvers differ in the last bits; Open3D itself is absent: parity with it unpinned)."""
+    """The product's OWN fit (f3d_obb_candidates_dev + f3d_obb_fit_dev in one batch, no box_fn) end to end against the oracle's literal
+    restatement of merge_bb.  Two comparisons:
+    (1) exact: the oracle's control flow calling the SAME GPU fit per instance on ALL members (host-pointer f3d_obb_fit) -- ids, areas,
+        entries and boxes bit for bit.  This pins the candidate pipeline (a box fitted on the hull candidates has the bits of a box fitted on
+        all members), the batched launch, the scans and the control flow.
+    (2) against the oracle with ITS fit (scipy Qhull + LAPACK): boxes equal as corner sets within 1e-8, and the merge decisions equal on
+        these seeded scenes.  (2) cannot be demanded of every scene: "the boxes share a cloud point" hangs on points ON a box face -- the
+        vertices that define a box's extents are in or out by the last bit of whoever computed the box (scripts/aux_fuzz.py: ~5 % of small
+        dense scenes differ, every flipped point within 3 ulp of a face; Open3D's own rounding would be a third opinion)."""
     import Fusion3DSeg.merge_intersecting_bb as M
+    ctx = f3d.default_context()
+
+    def gpu_fit(p):
+        boxes, status = ctx.obb_fit([p])
+        assert status[0] == f3d.OBB_OK
+        return boxes[0, 0:3].copy(), boxes[0, 3:12].reshape(3, 3).copy(), boxes[0, 12:15].copy()
     for B, n, seed in [(160, 40_000, 3456), (96, 150_000, 99)]:
         pts, ids, info = _c5_blobs(B, n, seed)
-        want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
         prof = {}
         keep = M._MergeState.__init__
 
@@ -413,11 +424,15 @@ def test_merge_bb_own_gpu_fit_end_to_end_against_the_oracle():
             got_info, got_ids = M.merge_bb(None, copy.deepcopy(info), ids.copy(), pts)
         finally:
             M._MergeState.__init__ = keep
-        assert np.array_equal(got_ids, want_ids) and len(got_info) < len(info)
-        assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info]
-        _same_boxes(got_info, want_info)
         st = prof['st'].prof
         assert st['nfit_gpu'] >= B - 2 and st['nfit_deferred'] == 0, st          # the fits really ran on the GPU
+        same_info, same_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts, box_fn=gpu_fit)          # (1)
+        assert np.array_equal(got_ids, same_ids) and len(got_info) < len(info)
+        assert json.dumps(got_info) == json.dumps(same_info)
+        want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)                          # (2)
+        assert np.array_equal(got_ids, want_ids)
+        assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info]
+        _same_boxes(got_info, want_info)
 
 
 def test_merge_bb_c5_recipe_with_the_oracles_fit_and_prefilter_off():
