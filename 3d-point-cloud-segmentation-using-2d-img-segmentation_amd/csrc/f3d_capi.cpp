@@ -583,8 +583,8 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
     if (coded) {
         void* tm;                                                                               // grows on first use only
         if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &tm))) return rc;
-        F3D_HIP(ctx, f3d_launch_code_masks(masks, (uint8_t*)tm, nviews, h, w, nclasses, fa, votes_u16 != nullptr, ctx->codebook, s));
-        F3D_HIP(ctx, f3d_launch_fuse_setup(views_dev, 0, nviews, tables, ctx->codebook, threshold, (unsigned int*)todo, s));
+        F3D_HIP(ctx, f3d_launch_code_masks_with_setup(masks, (uint8_t*)tm, nviews, h, w, nclasses, fa, votes_u16 != nullptr, ctx->codebook, views_dev, tables,
+                                                      threshold, (unsigned int*)todo, s));
         cmasks = (const uint8_t*)tm;
     }
     F3D_HIP(ctx, f3d_launch_fuse(xyz, dtype, n, views_dev, nviews, masks, cmasks, h, w, nclasses, fa, threshold, classes, votes_u16,

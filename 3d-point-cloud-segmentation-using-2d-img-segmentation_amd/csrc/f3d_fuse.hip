@@ -23,6 +23,14 @@
 #pragma clang fp contract(off)
 
 #define F3D_BLOCK 256
+#ifndef F3D_NT_CLASSES
+#define F3D_NT_CLASSES 1                 // the (scattered) label stores carry the non-temporal hint (measured: -2.5 % of the step)
+#endif
+#if F3D_NT_CLASSES
+#define F3D_STORE_CLASS(p, v) __builtin_nontemporal_store((int64_t)(v), (p))
+#else
+#define F3D_STORE_CLASS(p, v) (*(p) = (v))
+#endif
 
 namespace {
 
@@ -33,7 +41,6 @@ __device__ __forceinline__ f3d_p3 load_point(const T* __restrict__ xyz, int64_t 
     r.x = (double)p[0]; r.y = (double)p[1]; r.z = (double)p[2];
     return r;
 }
-
 enum { MODE_HIST8 = 0, MODE_HIST16 = 1 };
 
 // k-th entry of filter_classes: short lists travel in the kernarg, long ones in device memory
@@ -210,7 +217,7 @@ __device__ __forceinline__ void threshold_table(f3d_codebook* __restrict__ cb, d
 
 // one block of 256 threads: thread l decides the code of label l.  book: 0 = every label 0..nclasses has a bin (no
 // presence pass ran), 1 = presence book, 2 = filter book.
-__global__ __launch_bounds__(F3D_BLOCK) void k_code_lut(f3d_codebook* __restrict__ cb, int nclasses, int book, f3d_filter_args flt) {
+__device__ __forceinline__ void code_lut_block(f3d_codebook* __restrict__ cb, int nclasses, int book, const f3d_filter_args& flt) {
     __shared__ unsigned pres[8];
     __shared__ int first_of[256];                                  // filter book: position of label l's first occurrence, -1 = not listed
     const unsigned l = threadIdx.x;
@@ -247,6 +254,10 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_code_lut(f3d_codebook* __restrict
     cb->lut[l] = (uint8_t)code;
     if (code >= 2u) cb->inv[code] = (uint8_t)l;
     if (l == 0) { cb->ncodes = K + 2; cb->words = (K + 2 + 3) >> 2; cb->book = book; }
+}
+
+__global__ __launch_bounds__(F3D_BLOCK) void k_code_lut(f3d_codebook* __restrict__ cb, int nclasses, int book, f3d_filter_args flt) {
+    code_lut_block(cb, nclasses, book, flt);
 }
 
 // [V,H,W] row-major labels -> [V][ceil(H/8) + 2][ceil(W/8) + 2][8][8] bin codes (border tiles = "no sample"); one thread moves one
@@ -483,7 +494,7 @@ __device__ __forceinline__ void finish_point(const vote_state<MODE>& st, const u
         win_c = (int)(st.best >> 16); win_i = (int)(0xFFFFu - (st.best & 0xFFFFu));
     }
     const int64_t cls = segment_point(win_c, win_i, st.total, flt.nfilter, [&](int k) { return filter_at(flt, k); }, nclasses, threshold);
-    if (store) classes[orig] = cls;
+    if (store) F3D_STORE_CLASS(&classes[orig], cls);
     if (WRITE_VOTES && store) {
         for (int l = 0; l < ncols; ++l)
             votes_out[(size_t)orig * ncols + l] =
@@ -527,7 +538,7 @@ __device__ __forceinline__ void finish_bin32(const uint32_t* hcol, int ncodes, c
         win_c = (int)(best >> 8); win_i = (int)inv[best & 0xFFu];
     }
     const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold, cmin);
-    if (store) classes[orig] = cls;
+    if (store) F3D_STORE_CLASS(&classes[orig], cls);
     if (WRITE_VOTES && store) {
         for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? hcol[b * F3D_BLOCK] : 0u); }
     }
@@ -607,7 +618,7 @@ __device__ __forceinline__ bool finish_coded(unsigned nvalid, const uint32_t* hc
     }
     // total = the votes cast (every bin but "no sample"; a rejected label raises IndexError anyway)
     const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold, cmin);
-    if (store) classes[orig] = cls;
+    if (store) F3D_STORE_CLASS(&classes[orig], cls);
     if (WRITE_VOTES && store) {                                                    // presence book: an absent label reads bin 0 = 0
         for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? coded_count(hcol, b) : 0u); }
     }
@@ -695,13 +706,16 @@ __device__ __forceinline__ void wave_box(float& lo0, float& hi0, float& lo1, flo
 __device__ __forceinline__ void threshold_table(f3d_codebook* __restrict__ cb, double threshold);
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_setup(const f3d_view* __restrict__ views, int nviews, float* __restrict__ ctabT,
                                                            double* __restrict__ vtabT, f3d_codebook* __restrict__ cb, double threshold,
-                                                           unsigned int* __restrict__ todo_count) {
+                                                           unsigned int* __restrict__ todo_count, int lut_nclasses, int lut_book, f3d_filter_args flt) {
+    // (the one-shot call builds the code book in the same launch: its last block is k_code_lut's block -- one launch less per step)
+    if (lut_book >= 0 && blockIdx.x == gridDim.x - 1) { code_lut_block(cb, lut_nclasses, lut_book, flt); return; }
     if (blockIdx.x == 0) {
         threshold_table(cb, threshold);                       // ... the call's threshold table (segment_point)
         if (todo_count && threadIdx.x < 4) todo_count[threadIdx.x] = 0u;   // ... and empty deferred lists
     }
     const int ngroups = (nviews + 63) >> 6;
-    for (int k = blockIdx.x * F3D_BLOCK + threadIdx.x; k < ngroups * 64 * 39; k += gridDim.x * F3D_BLOCK) {
+    const int nsetup = lut_book >= 0 ? (int)gridDim.x - 1 : (int)gridDim.x;
+    for (int k = blockIdx.x * F3D_BLOCK + threadIdx.x; k < ngroups * 64 * 39; k += nsetup * F3D_BLOCK) {
         const int v = k / 39, f = k - v * 39, g = v >> 6, l = v & 63;
         const f3d_view& vw = views[v < nviews ? v : nviews - 1];
         if (f < 24) ctabT[(g * 24 + f) * 64 + l] = reinterpret_cast<const float*>(&vw.cull_n32[0][0])[f];
@@ -1400,6 +1414,18 @@ hipError_t f3d_launch_code_planes(const uint8_t* src, uint8_t* dst, int nviews, 
     return hipGetLastError();
 }
 
+// the one-shot call: presence -> [setup + book in one launch] -> coded planes
+hipError_t f3d_launch_code_masks_with_setup(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, const f3d_filter_args& flt,
+                                            bool want_votes, f3d_codebook* cb, const f3d_view* views_dev, void* tables, double threshold,
+                                            unsigned int* todo_count, hipStream_t s) {
+    if (nviews <= 0) return hipSuccess;
+    if (nclasses < 0 || nclasses > F3D_CODE_MAX_NCLASSES || ((uintptr_t)dst & 7)) return hipErrorInvalidValue;
+    hipError_t e;
+    if (pick_book(flt, want_votes) == 1 && (e = f3d_launch_mask_presence(src, (int64_t)nviews * h * w, cb, s)) != hipSuccess) return e;
+    if ((e = f3d_launch_fuse_setup(views_dev, 0, nviews, tables, cb, threshold, todo_count, s, nclasses, &flt, want_votes)) != hipSuccess) return e;
+    return f3d_launch_code_planes(src, dst, nviews, h, w, cb, s);
+}
+
 hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, const f3d_filter_args& flt,
                                  bool want_votes, f3d_codebook* cb, hipStream_t s) {
     if (nviews <= 0) return hipSuccess;
@@ -1511,12 +1537,16 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
 // transposed per-view tables of the views [v0, v1) the large-alphabet instances read (tables: f3d_fuse_tables_bytes(nviews) of scratch).
 // todo_count (the 4 counters of the deferred lists; NULL for a later chunk of a view-chunked call) is zeroed here.
 hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold,
-                                 unsigned int* todo_count, hipStream_t s) {
+                                 unsigned int* todo_count, hipStream_t s, int book_nclasses, const f3d_filter_args* book_flt, bool book_want_votes) {
+    // book_flt != NULL: the code book (f3d_launch_code_book's work) is built by an extra block of the same launch
     const int cnv = v1 - v0;
     if (cnv <= 0) return hipSuccess;
     float* ctabT = reinterpret_cast<float*>(tables);
     double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((cnv + 63) / 64) * 64 * 24 * sizeof(float));
-    hipLaunchKernelGGL(k_fuse_setup, dim3(8), dim3(F3D_BLOCK), 0, s, views_dev + v0, cnv, ctabT, vtabT, cb, threshold, todo_count);
+    f3d_filter_args none; none.nfilter = 0; none.cls_dev = nullptr; for (int k = 0; k < 8; ++k) none.cls[k] = -1;
+    if (book_flt && (book_nclasses < 0 || book_nclasses > F3D_CODE_MAX_NCLASSES)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fuse_setup, dim3(book_flt ? 9 : 8), dim3(F3D_BLOCK), 0, s, views_dev + v0, cnv, ctabT, vtabT, cb, threshold, todo_count,
+                       book_nclasses, book_flt ? pick_book(*book_flt, book_want_votes) : -1, book_flt ? *book_flt : none);
     return hipGetLastError();
 }
 

@@ -74,7 +74,11 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
                            int v0, int v1, uint32_t* carry /* NULL: all views in one launch */, void* xyz_keep, hipStream_t s);
 size_t f3d_fuse_tables_bytes(int nviews);
 hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void* tables, f3d_codebook* cb, double threshold,
-                                 unsigned int* todo_count /* zeroed; NULL: leave */, hipStream_t s);
+                                 unsigned int* todo_count, hipStream_t s, int book_nclasses = 0, const f3d_filter_args* book_flt = nullptr,
+                                 bool book_want_votes = false);
+hipError_t f3d_launch_code_masks_with_setup(const uint8_t* src, uint8_t* dst, int nviews, int h, int w, int nclasses, const f3d_filter_args& flt,
+                                            bool want_votes, f3d_codebook* cb, const f3d_view* views_dev, void* tables, double threshold,
+                                            unsigned int* todo_count /* NULL: leave the deferred lists' counters */, hipStream_t s);
 size_t f3d_fuse_carry_bytes(int64_t n, int nclasses);
 hipError_t f3d_launch_mask_presence(const uint8_t* src, int64_t nbytes, f3d_codebook* cb, hipStream_t s);
 hipError_t f3d_launch_presence_bytes(f3d_codebook* cb, uint8_t* bytes256, bool to_bytes, hipStream_t s);

@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--no-extras', action='store_true', help='skip the streaming-kernel measurements')
     ap.add_argument('--cpu-sample', type=int, default=5_000_000, help='points of the CPU-baseline slice (all views)')
     ap.add_argument('--sorted', action='store_true', help='experiment: hand the cloud over already in grid-cell order (host sort)')
+    ap.add_argument('--sorted-morton', type=int, default=0, metavar='BITS', help='experiment: hand the cloud over in Morton order with BITS bits per axis (host sort), no sort in the step')
     ap.add_argument('--no-sort', action='store_true', help='do not cell-sort the cloud inside the step')
     ap.add_argument('--prepared', action='store_true', help='cell-sort once outside the timed loop and keep the sorted cloud resident')
     ap.add_argument('--overlap-sort', action='store_true', help='sort the cloud of step i+1 on a second stream while step i is fused (measured: no '
@@ -360,6 +361,31 @@ def main():
     if args.sorted:
         cell = np.floor((xyz_np.astype(np.float64) - np.array([-5, -5, 0])) / 0.25).astype(np.int64)
         xyz_np = xyz_np[np.argsort((cell[:, 0] * 64 + cell[:, 1]) * 16 + cell[:, 2], kind='stable')]
+    if args.sorted_morton < 0:               # experiment: the device's 16-bit cell order (6, 6, 4 bits), then every 128-point wave-tile ordered by a fine Morton key
+        def morton(q, bits):
+            key = np.zeros(len(q), np.int64)
+            for level in range(max(bits) - 1, -1, -1):
+                for c in range(3):
+                    if bits[c] > level:
+                        key = (key << 1) | ((q[:, c] >> level) & 1)
+            return key
+        rel = (xyz_np.astype(np.float64) - np.array([-5, -5, 0])) / np.array([10.0, 10.0, 3.0])
+        coarse = morton(np.clip((rel * np.array([64, 64, 16])).astype(np.int64), 0, [63, 63, 15]), (6, 6, 4))
+        fine = morton(np.clip((rel * 1024).astype(np.int64), 0, 1023), (10, 10, 10))
+        order = np.argsort(coarse, kind='stable')
+        grp = np.arange(len(order)) // (-args.sorted_morton)
+        order = order[np.lexsort((fine[order], grp))]
+        xyz_np = xyz_np[order]
+        args.sorted = True
+    if args.sorted_morton > 0:
+        b = args.sorted_morton
+        q = np.clip(((xyz_np.astype(np.float64) - np.array([-5, -5, 0])) / 10.0 * (1 << b)).astype(np.int64), 0, (1 << b) - 1)
+        key = np.zeros(len(q), np.int64)
+        for level in range(b - 1, -1, -1):
+            for c in range(3):
+                key = (key << 1) | ((q[:, c] >> level) & 1)
+        xyz_np = xyz_np[np.argsort(key, kind='stable')]
+        args.sorted = True
     xyz = torch.from_numpy(xyz_np).to(dev)
     del xyz_np
     masks_np = synth.masks(V, S, S, args.masks)
