@@ -174,16 +174,24 @@ __device__ __forceinline__ int64_t rs_item(int64_t tile, int wave, int round, in
     return tile * RS_TILE + (int64_t)wave * (RS_ROUNDS * 64) + round * 64 + lane;
 }
 
-// keys of one tile + histogram of their low bytes.  blkhist is digit-major: [256][ntiles].
+// keys of one tile + histogram of their low bytes.  blkhist is digit-major: [256][ntiles].  The block shape is this kernel's own
+// (F3D_RK_THREADS threads walk the tile's 8192 points): measured 1024 / 512 / 256 / 128 / 64 threads = 76 / 64 / 57 / 74 / 114 us at 10M points --
+// 1221 blocks of 512 threads are 1.2 "waves" of resident blocks at 4 per CU (the last fifth runs on an empty chip), 256 threads all fit at once.
+#ifndef F3D_RK_THREADS
+#define F3D_RK_THREADS 256
+#endif
+constexpr int RK_THREADS = F3D_RK_THREADS;
+constexpr int RK_ROUNDS = RS_TILE / RK_THREADS;
+static_assert(RK_THREADS >= 64 && RK_THREADS * RK_ROUNDS == RS_TILE, "the key kernel's block must cover a tile");
 template <typename T>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_keys(const T* __restrict__ xyz, int64_t n, const bbox6* __restrict__ partial, int nparts,
+__global__ __launch_bounds__(RK_THREADS) void k_rs_keys(const T* __restrict__ xyz, int64_t n, const bbox6* __restrict__ partial, int nparts,
                                                          sort_key_t* __restrict__ keys, uint32_t* __restrict__ blkhist, int ntiles) {
     __shared__ uint32_t hist[256];
     __shared__ f3d_cellgrid sg;
     __shared__ uint16_t lut[3][RS_LUT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) grid_from_partials(partial, nparts, &sg);
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    for (int d = threadIdx.x; d < 256; d += RK_THREADS) hist[d] = 0u;
     __syncthreads();
     f3d_cellgrid g = sg;
 #pragma unroll
@@ -194,14 +202,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_keys(const T* __restrict__ xy
     const bool tables = g.dim[0] <= RS_LUT && g.dim[1] <= RS_LUT && g.dim[2] <= RS_LUT;
     if (tables) {                                                   // key = lut[0][ix] | lut[1][iy] | lut[2][iz]: three LDS reads instead of a 48-step bit loop
         for (int c = 0; c < 3; ++c)
-            for (int i = threadIdx.x; i < g.dim[c]; i += RS_THREADS) lut[c][i] = (uint16_t)spread_axis((uint32_t)i, c, g.bits);
+            for (int i = threadIdx.x; i < g.dim[c]; i += RK_THREADS) lut[c][i] = (uint16_t)spread_axis((uint32_t)i, c, g.bits);
         __syncthreads();
     }
     const float lo[3] = {(float)g.lo[0], (float)g.lo[1], (float)g.lo[2]};
     const float inv[3] = {(float)g.inv_cell[0], (float)g.inv_cell[1], (float)g.inv_cell[2]};
 #pragma unroll 8
-    for (int r = 0; r < RS_ROUNDS; ++r) {
-        const int64_t i = rs_item(blockIdx.x, wave, r, lane);
+    for (int r = 0; r < RK_ROUNDS; ++r) {
+        const int64_t i = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (RK_ROUNDS * 64) + r * 64 + lane;
         if (i < n) {
             uint32_t key;
             if (tables) {
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_keys(const T* __restrict__ xy
         }
     }
     __syncthreads();
-    if (threadIdx.x < 256) blkhist[(size_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+    for (int d = threadIdx.x; d < 256; d += RK_THREADS) blkhist[(size_t)d * ntiles + blockIdx.x] = hist[d];
 }
 
 // Pass 1 hands pass 2 ONE record per key: (high byte << 24) | index in 32 bits while the indices fit 24 bits (n <= 2^24: 4 B/point),
@@ -427,10 +435,10 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     const dim3 gt(L.ntiles), bt(RS_THREADS);
     if (dtype == F3D_F64) {
         hipLaunchKernelGGL(k_bbox_partial<double>, dim3(nparts), dim3(SB), 0, s, (const double*)xyz, n, stride, partial);
-        hipLaunchKernelGGL(k_rs_keys<double>, gt, bt, 0, s, (const double*)xyz, n, partial, nparts, keys, hist, L.ntiles);
+        hipLaunchKernelGGL(k_rs_keys<double>, gt, dim3(RK_THREADS), 0, s, (const double*)xyz, n, partial, nparts, keys, hist, L.ntiles);
     } else {
         hipLaunchKernelGGL(k_bbox_partial<float>, dim3(nparts), dim3(SB), 0, s, (const float*)xyz, n, stride, partial);
-        hipLaunchKernelGGL(k_rs_keys<float>, gt, bt, 0, s, (const float*)xyz, n, partial, nparts, keys, hist, L.ntiles);
+        hipLaunchKernelGGL(k_rs_keys<float>, gt, dim3(RK_THREADS), 0, s, (const float*)xyz, n, partial, nparts, keys, hist, L.ntiles);
     }
     hipError_t e = L.wide ? run_passes<uint64_t>(L, base, n, perm, s) : run_passes<uint32_t>(L, base, n, perm, s);
     if (e != hipSuccess) return e;

@@ -751,6 +751,16 @@ def test_unproject_depth_batch_equals_frame_by_frame():
         s.synchronize()
         assert np.array_equal(out.cpu().numpy(), want), code
         assert np.array_equal(want[2], ctx.unproject_depth(d[2], K, q[2], t[2]))
+    # more frames than one launch carries in its argument block (64): the call splits itself
+    F2, h2, w2 = 70, 5, 7
+    q2, t2 = rng.normal(size=(F2, 4)), rng.normal(size=(F2, 3))
+    d2 = rng.integers(0, 6000, (F2, h2, w2)).astype(np.uint16)
+    dd = torch.from_numpy(d2.view(np.int16)).to(dev)
+    out = torch.empty((F2, h2 * w2, 3), dtype=torch.float64, device=dev)
+    ctx.unproject_depth_batch_dev(dd.data_ptr(), 2, F2, h2, w2, K, q2, t2, out.data_ptr(), 1000.0, None)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.stack([O.unproject_depth(d2[f], K, q2[f], t2[f]) for f in range(F2)]))
+    ctx.unproject_depth_batch_dev(None, 2, 0, h2, w2, K, np.zeros((0, 4)), np.zeros((0, 3)), None, 1000.0, None)      # no frames: nothing happens
 
 
 def test_unproject_depth_matches_reference_golden(golden):
