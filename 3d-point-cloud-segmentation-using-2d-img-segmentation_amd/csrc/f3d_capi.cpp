@@ -961,10 +961,12 @@ int f3d_points_in_obb_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_
         return fail(ctx, F3D_ERR_INVALID, "points_in_obb: bad arguments (at most %d boxes per call)", F3D_OBB_MAX_BOXES);
     if (b == 0) return F3D_OK;
     hipStream_t s = pick(ctx, stream);
-    void* dboxes;                                              // the boxes, then their float32 bounds
-    if ((rc = ensure(ctx, SLOT_VIEWS, (sizeof(f3d_obb) + 6 * sizeof(float)) * (size_t)b, &dboxes))) return rc;
-    F3D_HIP(ctx, hipMemcpyAsync(dboxes, boxes, sizeof(f3d_obb) * (size_t)b, hipMemcpyHostToDevice, s));
-    F3D_HIP(ctx, f3d_launch_points_in_obb(xyz, dtype, n, (const f3d_obb*)dboxes, b, (float*)((char*)dboxes + sizeof(f3d_obb) * (size_t)b), inside_bits, cooc, s));
+    void* dboxes;                                              // the cell table (8-byte aligned), the boxes, then their float32 bounds
+    const size_t cells = f3d_obb_cells_bytes();
+    if ((rc = ensure(ctx, SLOT_VIEWS, cells + (sizeof(f3d_obb) + 6 * sizeof(float)) * (size_t)b, &dboxes))) return rc;
+    char* base = (char*)dboxes + cells;
+    F3D_HIP(ctx, hipMemcpyAsync(base, boxes, sizeof(f3d_obb) * (size_t)b, hipMemcpyHostToDevice, s));
+    F3D_HIP(ctx, f3d_launch_points_in_obb(xyz, dtype, n, (const f3d_obb*)base, b, (float*)(base + sizeof(f3d_obb) * (size_t)b), dboxes, inside_bits, cooc, s));
     return F3D_OK;
 }
 

@@ -142,8 +142,10 @@ hipError_t f3d_launch_vote_uv2pt_batch(const int32_t* luts, const uint8_t* masks
                                        int ncols, unsigned long long* table, uint64_t table_slots, unsigned gen, int frame0, int* first_bad,
                                        int* err, hipStream_t s);
 hipError_t f3d_launch_sem_to_mask(const float* sem, int nimg, int c, int64_t hw, float conf, int low_label, uint8_t* mask, hipStream_t s);
-// aabb: float [6 * b] of device scratch (the boxes' padded float32 bounds, filled by the launch)
-hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, float* aabb, uint32_t* bits,
+// aabb: float [6 * b] of device scratch (the boxes' padded float32 bounds, filled by the launch); cells: f3d_obb_cells_bytes() of
+// 8-byte aligned device scratch (the cell table of a call with 8 .. 64 boxes; NULL: every point visits every box)
+size_t f3d_obb_cells_bytes();
+hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, float* aabb, void* cells, uint32_t* bits,
                                     uint8_t* cooc, hipStream_t s);
 hipError_t f3d_launch_unproject_depth_batch(const void* depth, int depth_type, int nframes, int h, int w, const double K[9], double scale,
                                             const double* q_host, const double* t_host, double* out, hipStream_t s);

@@ -418,6 +418,138 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_obb_aabb(const f3d_obb* __restric
     }
 }
 
+// the in-box test both membership kernels share (one expression: the same roundings whichever kernel runs)
+__device__ __forceinline__ bool obb_inside(const f3d_p3& p, const obb_consts& bx) {
+    const double d0 = p.x - bx.c[0], d1 = p.y - bx.c[1], d2 = p.z - bx.c[2];
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double pr = (d0 * bx.R[a] + d1 * bx.R[3 + a]) + d2 * bx.R[6 + a];
+        in = in & (fabs(pr) <= bx.e[a] / 2);
+    }
+    return in;
+}
+
+// ---- cell table of the boxes (8 .. 64 boxes per call): which boxes can a point of cell c be in? ----
+// A grid of F3D_OBB_CELLS cells over the union of the boxes' (finite) bounds; cell c holds the bit set of the boxes whose padded
+// bounds meet the cell.  A point then tests only the boxes of its own cell -- for boxes that are small against the scene one or
+// two instead of all of them -- whatever order the cloud is in (the per-(wave, box) pre-test of k_points_in_obb prunes little when a
+// wave's 64 points are spread over the scene).  Results are those of the exact test alone: the table is a superset argument only.
+//   * a point's cell index is computed in float64 (error < 1e-14 cells); a cell's declared range is widened by 1e-6 cells + 2^-48 of the
+//     grid's coordinates, its outermost cells reach to infinity (points outside the grid clamp into them);
+//   * a box's float32 bounds contain every point the exact test accepts AFTER the point is rounded to float32 (k_obb_aabb's pad): as
+//     real intervals they are widened here by 2^-22 of their magnitude; infinite bounds (singular R) meet every cell.
+#define F3D_OBB_CELLS 2048
+#define F3D_OBB_CELL_MIN_BOXES 8
+struct obb_grid { double lo[3], inv[3]; int dim[3]; int pad; };
+
+__global__ __launch_bounds__(F3D_BLOCK) void k_obb_cells(const float* __restrict__ aabb, int B, obb_grid* __restrict__ grid,
+                                                          unsigned long long* __restrict__ table) {
+    __shared__ float sab[64 * 6];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < B * 6; k += F3D_BLOCK) sab[k] = aabb[k];
+    __syncthreads();
+    // union of the finite bounds (every thread: B <= 64, LDS broadcasts)
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < B; ++k) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float l = sab[6 * k + a], h = sab[6 * k + 3 + a];
+            if (l > -INFINITY && h < INFINITY) { lo[a] = fmin(lo[a], (double)l); hi[a] = fmax(hi[a], (double)h); }
+        }
+    }
+    double ext[3];
+    int dim[3] = {1, 1, 1};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { if (!(lo[a] <= hi[a])) { lo[a] = 0.0; hi[a] = 1.0; } ext[a] = hi[a] - lo[a]; }
+    for (int it = 0; it < 11; ++it) {                         // 2^11 cells: double the axis with the longest cells
+        const double s0 = ext[0] / dim[0], s1 = ext[1] / dim[1], s2 = ext[2] / dim[2];
+        if (s0 >= s1 && s0 >= s2) dim[0] *= 2; else if (s1 >= s2) dim[1] *= 2; else dim[2] *= 2;
+    }
+    double inv[3], h[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { h[a] = ext[a] / dim[a]; inv[a] = ext[a] > 0.0 ? dim[a] / ext[a] : 0.0; }
+    if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { grid->lo[a] = lo[a]; grid->inv[a] = inv[a]; grid->dim[a] = dim[a]; }
+        grid->pad = 0;
+    }
+    const int c = blockIdx.x * F3D_BLOCK + tid;
+    if (c >= F3D_OBB_CELLS) return;
+    const int ci[3] = {c % dim[0], (c / dim[0]) % dim[1], c / (dim[0] * dim[1])};
+    double clo[3], chi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double slack = 1e-6 * h[a] + 0x1p-48 * (fabs(lo[a]) + fabs(hi[a]));
+        clo[a] = (ci[a] == 0 || inv[a] == 0.0) ? -INFINITY : lo[a] + ci[a] * h[a] - slack;
+        chi[a] = (ci[a] == dim[a] - 1 || inv[a] == 0.0) ? INFINITY : lo[a] + (ci[a] + 1) * h[a] + slack;
+    }
+    unsigned long long m = 0ull;
+    for (int k = 0; k < B; ++k) {
+        bool meet = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double l = sab[6 * k + a], u = sab[6 * k + 3 + a];
+            const double sk = 0x1p-22 * fmax(fabs(l), fabs(u));
+            meet = meet & (l - sk <= chi[a]) & (u + sk >= clo[a]);
+        }
+        m |= meet ? (1ull << k) : 0ull;
+    }
+    table[c] = m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb_cells(const T* __restrict__ xyz, int64_t n, const f3d_obb* __restrict__ boxes, int B,
+                                                                    const obb_grid* __restrict__ grid, const unsigned long long* __restrict__ table,
+                                                                    uint32_t* __restrict__ bits, uint8_t* __restrict__ cooc) {
+    __shared__ unsigned long long stab[F3D_OBB_CELLS];      // 16 KB
+    __shared__ double sbox[64 * 15];                        // 7.5 KB: the boxes as they lie in memory (center, R, extent)
+    const int tid = threadIdx.x;
+    for (int k = tid; k < F3D_OBB_CELLS; k += F3D_BLOCK) stab[k] = table[k];
+    for (int k = tid; k < B * 15; k += F3D_BLOCK) sbox[k] = reinterpret_cast<const double*>(boxes)[k];
+    const double l0 = grid->lo[0], l1 = grid->lo[1], l2 = grid->lo[2], v0 = grid->inv[0], v1 = grid->inv[1], v2 = grid->inv[2];
+    const int n0 = grid->dim[0], n1 = grid->dim[1], n2 = grid->dim[2];
+    __syncthreads();
+    const int words = (B + 31) >> 5;
+    const int64_t ntiles = (n + F3D_BLOCK - 1) / F3D_BLOCK;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * F3D_BLOCK + tid;
+        const bool live = i < n;
+        f3d_p3 p = {0, 0, 0};
+        if (live) p = load_point(xyz, i);
+        auto cell1 = [](double x, double lo, double inv, int dim) {
+            const double t = (x - lo) * inv;
+            return t >= (double)dim ? dim - 1 : (t > 0.0 ? (int)t : 0);          // NaN: 0
+        };
+        const int c = cell1(p.x, l0, v0, n0) + n0 * (cell1(p.y, l1, v1, n1) + n1 * cell1(p.z, l2, v2, n2));
+        unsigned long long m = live ? stab[c] : 0ull, res = 0ull;
+        while (m) {                                          // per lane: the boxes of this point's cell
+            const int k = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const double* bp = sbox + 15 * k;
+            obb_consts bx;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { bx.c[j] = bp[j]; bx.e[j] = bp[12 + j]; }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) bx.R[j] = bp[3 + j];
+            res |= obb_inside(p, bx) ? (1ull << k) : 0ull;
+        }
+        if (live && bits) {
+            bits[(size_t)i * words] = (uint32_t)res;
+            if (words > 1) bits[(size_t)i * words + 1] = (uint32_t)(res >> 32);
+        }
+        if (cooc && res) {
+            for (unsigned long long a = res; a; a &= a - 1ull) {
+                const size_t ia = (size_t)__builtin_ctzll(a);
+                for (unsigned long long cc = res; cc; cc &= cc - 1ull) {
+                    const size_t ic = (size_t)__builtin_ctzll(cc);
+                    if (!cooc[ia * B + ic]) cooc[ia * B + ic] = 1;
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb(const T* __restrict__ xyz, int64_t n,
                                                               const f3d_obb* __restrict__ boxes, int B, const float* __restrict__ aabb,
@@ -447,14 +579,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_points_in_obb(const T* __restrict
                 if (!__any(near)) continue;                              // wave-uniform: a scalar branch
                 obb_consts bx = load_obb(boxes[w0 + k]);
                 pin(bx);
-                const double d0 = p.x - bx.c[0], d1 = p.y - bx.c[1], d2 = p.z - bx.c[2];
-                bool in = near;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double pr = (d0 * bx.R[a] + d1 * bx.R[3 + a]) + d2 * bx.R[6 + a];
-                    in = in & (fabs(pr) <= bx.e[a] / 2);
-                }
-                word |= in ? (1u << (k & 31)) : 0u;
+                word |= (near & obb_inside(p, bx)) ? (1u << (k & 31)) : 0u;
             }
             myb[(w0 >> 5) * F3D_BLOCK + tid] = word;
             any |= word;
@@ -639,7 +764,9 @@ hipError_t f3d_launch_sem_to_mask(const float* sem, int nimg, int c, int64_t hw,
     return hipGetLastError();
 }
 
-hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, float* aabb, uint32_t* bits,
+size_t f3d_obb_cells_bytes() { return sizeof(obb_grid) + (size_t)F3D_OBB_CELLS * sizeof(unsigned long long); }
+
+hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const f3d_obb* boxes_dev, int b, float* aabb, void* cells, uint32_t* bits,
                                     uint8_t* cooc, hipStream_t s) {
     if (n <= 0 || b <= 0) return hipSuccess;
     if (b > F3D_OBB_MAX_BOXES) return hipErrorInvalidValue;
@@ -648,8 +775,16 @@ hipError_t f3d_launch_points_in_obb(const void* xyz, int dtype, int64_t n, const
         hipError_t e = hipMemsetAsync(cooc, 0, (size_t)b * b, s);
         if (e != hipSuccess) return e;
     }
-    const size_t lds = (size_t)((b + 31) / 32) * F3D_BLOCK * sizeof(uint32_t);
     const dim3 g(grid_for(n, F3D_BLOCK, F3D_GRID_CAP)), blk(F3D_BLOCK);
+    if (b >= F3D_OBB_CELL_MIN_BOXES && b <= 64 && cells) {     // a point visits the boxes of its cell only
+        obb_grid* grid = reinterpret_cast<obb_grid*>(cells);
+        unsigned long long* table = reinterpret_cast<unsigned long long*>(grid + 1);
+        hipLaunchKernelGGL(k_obb_cells, dim3(F3D_OBB_CELLS / F3D_BLOCK), blk, 0, s, aabb, b, grid, table);
+        if (dtype == F3D_F64) hipLaunchKernelGGL(k_points_in_obb_cells<double>, g, blk, 0, s, (const double*)xyz, n, boxes_dev, b, grid, table, bits, cooc);
+        else hipLaunchKernelGGL(k_points_in_obb_cells<float>, g, blk, 0, s, (const float*)xyz, n, boxes_dev, b, grid, table, bits, cooc);
+        return hipGetLastError();
+    }
+    const size_t lds = (size_t)((b + 31) / 32) * F3D_BLOCK * sizeof(uint32_t);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (dtype == F3D_F64) {
         if (lds > 48 * 1024) {                             // beyond the default dynamic-LDS limit: the launch needs the attribute

@@ -432,7 +432,7 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     const int64_t sb = ((n + stride - 1) / stride + SB - 1) / SB;
     const int nparts = (int)(sb < 64 ? sb : 64);                 // (one lane of k_rs_keys' first wave per partial box)
     const int gstream = (int)(gb < 8192 ? gb : 8192);
-    const dim3 gt(L.ntiles), bt(RS_THREADS);
+    const dim3 gt(L.ntiles);
     if (dtype == F3D_F64) {
         hipLaunchKernelGGL(k_bbox_partial<double>, dim3(nparts), dim3(SB), 0, s, (const double*)xyz, n, stride, partial);
         hipLaunchKernelGGL(k_rs_keys<double>, gt, dim3(RK_THREADS), 0, s, (const double*)xyz, n, partial, nparts, keys, hist, L.ntiles);

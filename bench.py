@@ -698,7 +698,7 @@ def main():
         tk = time_kernel(torch, lambda: ctx.points_in_obb_dev(xyz.data_ptr(), dtype, n, boxes, None, cooc.data_ptr(), stream.cuda_stream), 5, stream)
         extras['points_in_obb (a10/a11, 64 boxes)'] = dict(ms=round(tk * 1e3, 4), point_box_tests_per_s=round(64 * n / tk, 1),
                                                            GBps=round(xyz_b * n / tk / 1e9, 1), hbm_frac=round(xyz_b * n / tk / 1e9 / HBM_PEAK_GBS, 4),
-                                                           note='per (wave, box) a float32 test against the box bounds first; the float64 in-box test (27 flop) only for waves with a point inside them')
+                                                           note='8..64 boxes: a 2048-cell table over the boxes\' bounds (k_obb_cells), a point runs the float64 in-box test (27 flop) only for the boxes of its cell; other box counts: per (wave, box) a float32 bounds test first')
         del ins, cooc
         out['streaming_kernels'] = extras
 

@@ -137,6 +137,60 @@ def test_points_in_obb_large_and_ragged_box_counts(B):
     assert inside2[:, :3].any()
 
 
+@pytest.mark.parametrize('B', [8, 33, 64])
+def test_points_in_obb_cell_table_path(B):
+    """8 .. 64 boxes per call: a point visits only the boxes registered in its cell of a 2048-cell grid over the boxes' bounds
+    (k_obb_cells / k_points_in_obb_cells).  The table must never hide a box: points outside the grid, on cell faces, non-finite points,
+    a scene far from the origin (float32 bounds are coarse there), boxes that are all the same, boxes with infinite bounds."""
+    ctx = f3d.default_context()
+    rng = np.random.default_rng(100 + B)
+
+    def check(pts, boxes, dtype=np.float64):
+        with np.errstate(all='ignore'):
+            inside, cooc = ctx.points_in_obb(pts.astype(dtype), boxes)
+            p64 = pts.astype(dtype).astype(np.float64)
+            want = np.stack([O.points_in_obb(p64, b[0:3], b[3:12].reshape(3, 3), b[12:15]) for b in boxes], axis=1)
+        assert np.array_equal(inside, want)
+        m = want.astype(np.float32)
+        assert np.array_equal(cooc, (m.T @ m) > 0)
+        return want
+
+    def random_boxes(centre, spread, lo_e, hi_e):
+        boxes = np.zeros((B, 15))
+        boxes[:, 0:3] = centre + rng.uniform(-1, 1, (B, 3)) * spread
+        for k in range(B):
+            boxes[k, 3:12] = np.linalg.qr(rng.normal(size=(3, 3)))[0].reshape(-1)
+        boxes[:, 12:15] = rng.uniform(lo_e, hi_e, (B, 3))
+        return boxes
+
+    boxes = random_boxes(np.array([0.0, 0.0, 1.5]), np.array([5.0, 5.0, 1.5]), 0.2, 1.5)
+    pts = rng.uniform([-8, -8, -2], [8, 8, 5], (60_000, 3))                       # a third of them outside the grid
+    pts[:5] = [[np.nan, 0, 0], [np.inf, 0, 1], [0, -np.inf, 1], [1e300, 1e300, 1e300], [0, 0, np.nan]]
+    # points exactly on box centres, box corners and (nearly) on faces
+    pts[5:5 + B] = boxes[:, 0:3]
+    from Fusion3DSeg.merge_intersecting_bb import obb_corners
+    pts[100:108] = obb_corners(boxes[0, 0:3], boxes[0, 3:12].reshape(3, 3), boxes[0, 12:15])
+    face = boxes[1, 0:3] + boxes[1, 3:12].reshape(3, 3)[:, 0] * boxes[1, 12] / 2
+    pts[110:120] = face + np.outer(np.arange(-5, 5) * 1e-16, boxes[1, 3:12].reshape(3, 3)[:, 0])
+    want = check(pts, boxes)
+    assert want.any(0).all() and want[5:5 + B].any(1).all()
+    check(pts, boxes, np.float32)
+    # the same scene 1e6 away from the origin: the float32 bounds and a float32 cloud are coarse (0.06 m), the table has to allow for it
+    off = np.array([1.0e6, -2.0e6, 3.0e5])
+    far = boxes.copy(); far[:, 0:3] += off
+    assert check(pts[120:] + off, far).any()
+    assert check(pts[120:] + off, far, np.float32).any()
+    # all boxes the same (a grid of no extent along any axis), and boxes without usable bounds among ordinary ones
+    same = np.repeat(boxes[:1], B, axis=0)
+    assert check(pts, same).all(1).any()
+    odd = boxes.copy()
+    odd[2, 3:12] = np.array([[1, 2, 3], [2, 4, 6], [0, 0, 1.0]]).reshape(-1)      # singular: infinite bounds
+    odd[4, 3] = np.nan
+    odd[6, 12:15] = [1e9, 1e9, 1e9]                                               # contains everything finite
+    w = check(pts, odd)
+    assert w[5:, 6].sum() >= len(pts) - 6
+
+
 def _rank_labels(rank, world, port, n, out_dir):
     """One rank of the point-sharded step: HIP labels of its shard, masks all-gathered over the process group."""
     import torch
