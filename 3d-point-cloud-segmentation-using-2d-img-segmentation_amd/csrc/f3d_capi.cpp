@@ -264,15 +264,13 @@ int f3d_ctx_synchronize(f3d_ctx* ctx) {
 
 void* f3d_ctx_stream(f3d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-static size_t fuse_todo_bytes(int64_t n) { return 16 + (size_t)n * 8; }     // 4 counters + two index lists (fast -> mid -> exact)
-
 int f3d_ctx_reserve(f3d_ctx* ctx, int64_t n, int nviews, int h, int w) {
     int rc = enter(ctx); if (rc) return rc;
     if (n < 0 || n > 0x7fffffffLL || nviews < 0 || h < 0 || w < 0) return fail(ctx, F3D_ERR_INVALID, "ctx_reserve: bad arguments");
     const int strict = ctx->strict;
     ctx->strict = 0;
     void* p;
-    rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &p);
+    rc = ensure(ctx, SLOT_TODO, f3d_fuse_todo_bytes(n, nviews, F3D_CODE_MAX_NCLASSES), &p);   // (any number of classes)
     if (!rc && n > 0) rc = ensure(ctx, SLOT_SORT_PERM, (size_t)n * 4, &p);
     if (!rc && n > 0) rc = ensure(ctx, SLOT_SORT_SCRATCH, f3d_sort_scratch_bytes(n), &p);
     if (!rc && nviews > 0 && h > 0 && w > 0) rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &p);
@@ -578,7 +576,7 @@ int f3d_project_vote_argmax_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, 
     }
     const uint8_t* cmasks = nullptr;                                                            // coded, tiled copy for the fast kernel
     void *todo, *tables;                                                                        // grow on first use only
-    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
+    if ((rc = ensure(ctx, SLOT_TODO, f3d_fuse_todo_bytes(n, nviews, nclasses), &todo))) return rc;
     if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews > 0 ? nviews : 1), &tables))) return rc;
     if (coded) {
         void* tm;                                                                               // grows on first use only
@@ -616,7 +614,7 @@ int f3d_fuse_chunked_begin_dev(f3d_ctx* ctx, const uint8_t* present256, int64_t 
     if ((rc = make_filter(ctx, filter, nfilter, nclasses + 1, true, s, &fa))) return rc;
     void* p;                                                   // every scratch buffer of the chunk calls: they allocate nothing
     if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &p))) return rc;
-    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &p))) return rc;
+    if ((rc = ensure(ctx, SLOT_TODO, f3d_fuse_todo_bytes(n, nviews, nclasses), &p))) return rc;
     if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews), &p))) return rc;
     if ((rc = ensure(ctx, SLOT_FUSE_CARRY, f3d_fuse_carry_bytes(n, nclasses), &p))) return rc;
     if (n > 0) {                                               // F3D_FUSE_SORT / a gathered cloud: permutation, sort scratch, cell-order copy
@@ -697,7 +695,7 @@ static int fuse_chunk_impl(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64
     const bool cgather = ctx->chunk.gather != 0;
     void *tm, *todo, *tables, *carry;
     if ((rc = ensure(ctx, SLOT_TILED_MASKS, f3d_coded_masks_bytes(nviews, h, w), &tm))) return rc;
-    if ((rc = ensure(ctx, SLOT_TODO, fuse_todo_bytes(n), &todo))) return rc;
+    if ((rc = ensure(ctx, SLOT_TODO, f3d_fuse_todo_bytes(n, nviews, nclasses), &todo))) return rc;
     if ((rc = ensure(ctx, SLOT_FUSE_TABLES, f3d_fuse_tables_bytes(nviews), &tables))) return rc;
     if ((rc = ensure(ctx, SLOT_FUSE_CARRY, f3d_fuse_carry_bytes(n, nclasses), &carry))) return rc;
     const size_t plane = f3d_coded_masks_bytes(1, h, w);

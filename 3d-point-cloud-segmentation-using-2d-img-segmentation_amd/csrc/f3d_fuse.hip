@@ -19,6 +19,7 @@
 #include "f3d.h"
 #include "f3d_math.h"
 #include "f3d_kernels.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -738,7 +739,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                                                      unsigned int* __restrict__ todo_count, int32_t* __restrict__ todo,
                                                      const f3d_codebook* __restrict__ cb, int cmin, int cmax,
                                                      const float* __restrict__ ctabT, const double* __restrict__ vtabT,
-                                                     uint32_t* __restrict__ carry, int chunk_flags, T* __restrict__ xyz_keep) {
+                                                     uint32_t* __restrict__ carry, int chunk_flags, T* __restrict__ xyz_keep,
+                                                     unsigned long long* __restrict__ umask, uint32_t* __restrict__ park, int park_slots, int park_stride) {
     const int ncodes = cb->ncodes;                                        // wave-uniform: scalar load
     if (ncodes > cmax || ncodes < cmin) return;                           // the other instance's book
     const int words = (ncodes + 3) >> 2;
@@ -850,7 +852,17 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             if (!act[0]) { DX.x = __builtin_nanf(""); }
             if (!act[1]) { DX.y = __builtin_nanf(""); }
         }
-        unsigned unsure[2] = {0u, 0u};                       // a visible view left one of the point's decisions unproven
+        // PART (the instances of a call with at most 64 views, not view-chunked): a point with unproven decisions keeps the votes of its
+        // proven views.  um = the views that left one of the point's decisions unproven; at the end the point's bins are parked in
+        // park[slot] next to that mask, and the float64 tier visits the marked views only (typically one of 64).  Points without usable
+        // float32 coordinates, points beyond park_slots deferred ones, and every deferred point of the other instances are redone from
+        // nothing (sign bit of the list entry).
+        // (The dword-bin instance of a call with several view groups keeps the plain flag: the masks would cost it its fourth wave per SIMD;
+        // the other instances track the mask and use it when the call has one group.)
+        constexpr bool PART = !CARRY && !WRAP && (TLDS || !BIN32);
+        const bool part1 = PART && ngroups == 1;
+        unsigned long long um[2] = {0ull, 0ull};             // PART
+        unsigned unsure[2] = {0u, 0u};                       // !PART: a visible view left one of the point's decisions unproven
         if (CARRY && (chunk_flags & 1)) {                                   // the bins (and the deferred flag) of the earlier view chunks
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
@@ -939,7 +951,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #endif
             while (todo_v) {
                 int cbit[F3D_CHUNK]; unsigned coff[2][F3D_CHUNK];
-                bool use[F3D_CHUNK];
+                bool use[F3D_CHUNK], uns[2][F3D_CHUNK];
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) {
                     use[k] = todo_v != 0ull;
@@ -953,7 +965,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) {
-                        unsure[q] = safe[q] ? unsure[q] : 1u;                  // (an unused slot repeats a row of this chunk: same answer)
+                        if (PART) uns[q][k] = act[q] & !safe[q];               // (an unused slot repeats a row of this chunk: same answer)
+                        else unsure[q] = safe[q] ? unsure[q] : 1u;
                         const unsigned o = r.obase + rel_offset(fi0[q], fi1[q], c_row);   // computed for every lane: a select, not a branch
                         coff[q][k] = (safe[q] & use[k]) ? o : 0u;              // offset 0: a border tile, "no sample"
                     }
@@ -975,6 +988,17 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #endif
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = gather(coff[0][k]); if (PPL == 2) ccode[1][k] = gather(coff[1][k]); }
+                if (PART) {                                                    // rare: a lane mask test (scalar) in the common case
+                    bool au = false;
+#pragma unroll
+                    for (int k = 0; k < F3D_CHUNK; ++k) au = au | uns[0][k] | (PPL == 2 ? uns[1][k] : false);
+                    if (__any(au)) {
+#pragma unroll
+                        for (int k = 0; k < F3D_CHUNK; ++k)
+#pragma unroll
+                            for (int q = 0; q < PPL; ++q) um[q] |= uns[q][k] ? (1ull << cbit[k]) : 0ull;
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < F3D_CHUNK; ++k) {
@@ -1021,6 +1045,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 }
 #undef F3D_RL1
                 unsigned off[2] = {0u, 0u};
+                bool unsv[2] = {false, false};
                 if (has_row) {
                     centre_row r = read_row(mine, bit);
                     const int U8 = __builtin_amdgcn_readlane(mine.U8, bit), V8 = __builtin_amdgcn_readlane(mine.V8, bit);
@@ -1030,13 +1055,22 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     for (int q = 0; q < PPL; ++q) {
                         const bool inside = sure[q];
                         const bool hit = inside & safe[q] & ((unsigned)(fi0[q] + U8) < (unsigned)W) & ((unsigned)(fi1[q] + V8) < (unsigned)H);
-                        unsure[q] = ((maybe[q] & !sure[q]) | (inside & !safe[q])) ? 1u : unsure[q];
+                        unsv[q] = (maybe[q] & !sure[q]) | (inside & !safe[q]);
                         const unsigned o = r.obase + rel_offset(fi0[q], fi1[q], c_row);
                         off[q] = hit ? o : 0u;
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < PPL; ++q) unsure[q] = maybe[q] ? 1u : unsure[q];      // the box comes too close to this view's camera plane
+                    for (int q = 0; q < PPL; ++q) unsv[q] = maybe[q];                         // the box comes too close to this view's camera plane
+                }
+                if (PART) {
+                    if (__any(unsv[0] | unsv[1])) {                            // rare
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) um[q] |= unsv[q] ? (1ull << bit) : 0ull;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PPL; ++q) unsure[q] = unsv[q] ? 1u : unsure[q];
                 }
 #ifndef F3D_NO_VOTE_PIN
                 asm volatile("" : "+v"(pend[0]) : "v"(off[0]));
@@ -1049,7 +1083,9 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             vote(q, pend[q]);
-            defer[q] = defer[q] | (act[q] & (unsure[q] != 0u));
+            const bool part = act[q] & (PART ? um[q] != 0ull : unsure[q] != 0u);   // unproven views: the float64 tier adds their votes to the parked bins
+            bool full = defer[q] | (part & !part1);            // ... or redoes the point from nothing
+            defer[q] = defer[q] | part;
             uint32_t* hc = q ? hcol1 : hcol0;
             if (CARRY && (chunk_flags & 2)) {                                 // more views to come: park the bins in HBM
                 uint32_t* cq = carry + ((size_t)(tile * PPL + q) * words) * F3D_BLOCK + tid;
@@ -1070,8 +1106,27 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             if (BIN32) finish_bin32<WRITE_VOTES>(hc, ncodes, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q], classes, votes_out, bad, vmin);
             else trusted = finish_coded<WRITE_VOTES, WRAP>(nvalid[q], hc, words, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q],
                                                            classes, votes_out, bad, vmin);
-            const bool d = defer[q] | (live[q] & !trusted);
-            if (d) todo[atomicAdd(todo_count, 1u)] = gather_xyz ? orig[q] : (i0 + 64 * q);     // index into xyz as this launch sees it
+            full = full | (live[q] & !trusted);
+            const bool d = defer[q] | full;
+            if (d) {
+                const int sl = (int)atomicAdd(todo_count, 1u);
+                full = full | !part1 | (sl >= park_slots);
+                todo[sl] = (gather_xyz ? orig[q] : (i0 + 64 * q)) | (full ? (int)0x80000000 : 0);   // index into xyz as this launch sees it
+                if (PART && !full) {                                          // the bins, four 8-bit counts to a dword as the other tiers hold them
+                    umask[sl] = um[q];
+                    uint32_t* pk = park + (size_t)sl * park_stride;
+                    for (int wd = 0; wd < words; ++wd) {
+                        uint32_t x = 0u;
+                        if (BIN32) {
+#pragma unroll
+                            for (int b4 = 0; b4 < 4; ++b4) if (4 * wd + b4 < ncodes) x |= (hc[(4 * wd + b4) * F3D_BLOCK] & 0xFFu) << (8 * b4);
+                        } else {
+                            x = hc[wd * F3D_BLOCK];
+                        }
+                        pk[wd] = wd == 0 ? (x & ~0xFFu) : x;                  // ("no sample" is nobody's vote)
+                    }
+                }
+            }
             if (bad & !d) atomicOr(err, F3D_DEVERR_FUSE);
         }
     }
@@ -1130,72 +1185,139 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
                                                          int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
                                                          int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
                                                          unsigned int* __restrict__ out_count, int32_t* __restrict__ out_list,
-                                                         const f3d_codebook* __restrict__ cb) {
+                                                         const f3d_codebook* __restrict__ cb,
+                                                         const unsigned long long* __restrict__ umask, const uint32_t* __restrict__ park,
+                                                         int park_slots, int park_stride) {
+    // A block takes 256 deferred points at a time.  A point k_fuse parked (list entry without the sign bit, slot < park_slots) comes with
+    // the bins of its proven views and the mask of the views still to be decided -- typically ONE of 64; the others start from empty
+    // bins and need every view.  The (point, view) pairs of the 256 points are numbered through a block-wide prefix sum and dealt to the
+    // threads round robin: the points with many open views (all points of a wave whose box straddles a jump of the cell order) would
+    // otherwise hold their whole wave back.  A thread votes into the bins of the pair's point with LDS atomics; the view records are
+    // per-lane loads.  r3: 50 us (every deferred point over all 64 views, wave-uniform records) -> 35 us (a thread walks the open views
+    // of its own point) -> this form, at C3.
     extern __shared__ uint32_t lds_u32[];
     uint32_t* lutw = lds_u32;                                             // lut[256] then inv[256] (bytes)
-    uint32_t* hist = lutw + 128;                                          // [words][F3D_BLOCK]
+    uint32_t* spre = lutw + 128;                                          // [F3D_BLOCK + 4] exclusive prefix of the open views per point, wave totals
+    uint32_t* snv = spre + F3D_BLOCK + 4;                                 // [F3D_BLOCK] votes cast
+    uint32_t* sdefer = snv + F3D_BLOCK;                                   // [F3D_BLOCK] a decision this tier cannot prove either
+    unsigned long long* smask = reinterpret_cast<unsigned long long*>(sdefer + F3D_BLOCK);   // [F3D_BLOCK] open views of the current group
+    double* spt = reinterpret_cast<double*>(smask + F3D_BLOCK);          // [3][F3D_BLOCK] the points
+    uint32_t* hist = reinterpret_cast<uint32_t*>(spt + 3 * F3D_BLOCK);   // [words][F3D_BLOCK]
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(lutw);
     const uint8_t* inv = lut + 256;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int words = cb->words;
     const size_t plane = f3d_coded_plane(H, W);
     const int wt = f3d_coded_pitch(W);
     const unsigned none_off = 0u;                                         // a border tile: "no sample"
     const double umax = (double)(W > H ? W : H);
+    const int ngroups = (nviews + 63) >> 6;
     if (tid < 128) lutw[tid] = reinterpret_cast<const uint32_t*>(cb->lut)[tid];
-    __syncthreads();
     const int count = (int)*in_count;
-    for (int base = blockIdx.x * F3D_BLOCK; base < count; base += gridDim.x * F3D_BLOCK) {
+    for (int base = blockIdx.x * F3D_BLOCK; base < count; base += gridDim.x * F3D_BLOCK) {     // block-uniform bounds: every thread meets every barrier
         const int k = base + tid;
         const bool live = k < count;
-        const int src = live ? in_list[k] : 0;                                    // index into xyz as k_fuse saw it
-        const int orig = (live && perm && !gather_xyz) ? perm[src] : src;
-        f3d_p3 p = {0.0, 0.0, 0.0};
-        if (live) p = load_point(xyz, (int64_t)src);
-        const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
-        const bool small = pscale < 1.0e30;
-        const float px32 = (float)p.x, py32 = (float)p.y, pz32 = (float)p.z, ps32 = (float)pscale;
-        bool defer = EXACT ? false : (live & !small);
-        for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
-        // (a four-deep gather pipeline was measured: 50 us either way -- the loop is bound by the scalar loads of the view records and the
-        // float64 projection of a wave with 2 waves per SIMD resident, not by the gather latency)
-        unsigned nvalid = 0, pend_code = F3D_CODE_NONE;
-        for (int v = 0; v < nviews; ++v) {
-            const f3d_view& vw = views[v];                                        // wave-uniform: scalar loads
-            bool hit = false;
-            int iu = 0, iv = 0;
-            if (EXACT) {
-                if (live && f3d_inside_view(vw, p)) {
-                    double fu, fv;
-                    project_exact(vw, p, fu, fv);
-                    if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) { hit = true; iu = (int)fu; iv = (int)fv; }   // NaN compares false
+        const int entry = live ? in_list[k] : 0;
+        const int src = entry & 0x7fffffff;                                       // index into xyz as k_fuse saw it
+        const bool full = EXACT | (entry < 0) | (k >= park_slots) | (umask == nullptr);
+        {
+            f3d_p3 p = {0.0, 0.0, 0.0};
+            if (live) p = load_point(xyz, (int64_t)src);
+            spt[tid] = p.x; spt[F3D_BLOCK + tid] = p.y; spt[2 * F3D_BLOCK + tid] = p.z;
+            const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
+            sdefer[tid] = (!EXACT && live && !(pscale < 1.0e30)) ? 1u : 0u;
+            unsigned nv0 = 0;
+            if (live && !full) {                                                  // the votes of the views k_fuse proved
+                const uint32_t* pk = park + (size_t)k * park_stride;
+                for (int wd = 0; wd < words; ++wd) {
+                    const uint32_t x = pk[wd];
+                    hist[wd * F3D_BLOCK + tid] = x;
+                    nv0 = __builtin_amdgcn_sad_u8(x, 0u, nv0);                    // (byte 0 of word 0, "no sample", is parked as 0)
                 }
             } else {
-                bool maybe, sure;
-                cull_point32(load_cull(vw), px32, py32, pz32, ps32, small, maybe, sure);
-                bool inside = live & small & sure;
-                if (live & small & maybe & !sure) {                               // inside the float32 margin: decide with float64 FMAs
-                    bool m64, s64;
-                    cull_point64(vw, p, pscale, m64, s64);
-                    inside = s64;
-                    defer = defer | (m64 & !s64);                                 // within rounding of the plane itself
-                }
-                if (inside) {
-                    bool unsure;
-                    hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
-                    defer = defer | unsure;
-                }
+                for (int wd = 0; wd < words; ++wd) hist[wd * F3D_BLOCK + tid] = 0u;
             }
-            vote_coded<true>(nvalid, hist + tid, pend_code);
-            pend_code = (cmasks + (size_t)v * plane)[hit ? mask_offset<true>(iu, iv, wt) : none_off];
+            snv[tid] = nv0;
         }
-        vote_coded<true>(nvalid, hist + tid, pend_code);
+        for (int g = 0; g < ngroups; ++g) {
+            const int nvg = min(64, nviews - 64 * g);
+            unsigned long long m = !live ? 0ull : full ? (nvg == 64 ? ~0ull : (1ull << nvg) - 1ull) : umask[(size_t)k * ngroups + g];
+#if defined(F3D_EXP_MID) && F3D_EXP_MID == 1          // timing experiment: no view work at all
+            m = 0ull;
+#elif defined(F3D_EXP_MID) && F3D_EXP_MID == 2        // timing experiment: one view per point at most
+            m &= 0ull - m;
+#endif
+            // exclusive prefix of the open-view counts over the block
+            const unsigned c = (unsigned)__builtin_popcountll(m);
+            unsigned incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(incl, off, 64); incl += lane >= off ? o : 0u; }
+            __syncthreads();                                              // (the previous round's readers of smask / spre are done)
+            smask[tid] = m;
+            if (lane == 63) spre[F3D_BLOCK + wv] = incl;
+            __syncthreads();
+            unsigned wbase = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < F3D_BLOCK / 64; ++w) { const unsigned t = spre[F3D_BLOCK + w]; wbase += w < wv ? t : 0u; total += t; }
+            spre[tid] = wbase + incl - c;
+            __syncthreads();
+            unsigned pend_code = F3D_CODE_NONE;
+            int pend_pt = 0;
+            auto cast = [&](int pt, unsigned b) {                             // several threads may vote for one point: LDS atomics
+                if (b != F3D_CODE_NONE) { atomicAdd(&snv[pt], 1u); atomicAdd(&hist[(b >> 2) * F3D_BLOCK + pt], 1u << ((b & 3u) * 8u)); }
+            };
+            for (unsigned j = tid; j < total; j += F3D_BLOCK) {
+                int lo = 0;                                                   // the last point whose prefix is <= j (points without open views are skipped by it)
+#pragma unroll
+                for (int step = F3D_BLOCK / 2; step >= 1; step >>= 1) lo += (spre[lo + step] <= j) ? step : 0;
+                unsigned long long mm = smask[lo];
+                for (unsigned r = j - spre[lo]; r > 0; --r) mm &= mm - 1ull;
+                const int v = 64 * g + __builtin_ctzll(mm);
+                const f3d_p3 p = {spt[lo], spt[F3D_BLOCK + lo], spt[2 * F3D_BLOCK + lo]};
+                const f3d_view& vw = views[v];
+                bool hit = false, defer = false;
+                int iu = 0, iv = 0;
+                if (EXACT) {
+                    if (f3d_inside_view(vw, p)) {
+                        double fu, fv;
+                        project_exact(vw, p, fu, fv);
+                        if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) { hit = true; iu = (int)fu; iv = (int)fv; }   // NaN compares false
+                    }
+                } else {
+                    const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
+                    const bool small = pscale < 1.0e30;
+                    bool maybe, sure;
+                    cull_point32(load_cull(vw), (float)p.x, (float)p.y, (float)p.z, (float)pscale, small, maybe, sure);
+                    bool inside = small & sure;
+                    if (small & maybe & !sure) {                                  // inside the float32 margin: decide with float64 FMAs
+                        bool m64, s64;
+                        cull_point64(vw, p, pscale, m64, s64);
+                        inside = s64;
+                        defer = m64 & !s64;                                       // within rounding of the plane itself
+                    }
+                    if (inside) {
+                        bool unsure;
+                        hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
+                        defer = defer | unsure;
+                    }
+                    if (defer) atomicOr(&sdefer[lo], 1u);
+                }
+                cast(pend_pt, pend_code);
+                pend_code = (cmasks + (size_t)v * plane)[hit ? mask_offset<true>(iu, iv, wt) : none_off];
+                pend_pt = lo;
+            }
+            cast(pend_pt, pend_code);
+        }
+        __syncthreads();                                                  // every vote is in
+        const int orig = (live && perm && !gather_xyz) ? perm[src] : src;
+        bool defer = sdefer[tid] != 0u;
         bool bad = false;
-        const bool trusted = finish_coded<WRITE_VOTES, true>(nvalid, hist + tid, words, lut, inv, nfilter, fcls, nclasses, threshold,
+        const bool trusted = finish_coded<WRITE_VOTES, true>(snv[tid], hist + tid, words, lut, inv, nfilter, fcls, nclasses, threshold,
                                                              live & !defer, orig, classes, votes_out, bad);
         defer = defer | (live & !trusted);
         if (!EXACT && defer) out_list[atomicAdd(out_count, 1u)] = src;
         if (bad & !defer) atomicOr(err, F3D_DEVERR_FUSE);
+        __syncthreads();                                                  // (the next round overwrites the bins)
     }
 }
 
@@ -1436,6 +1558,24 @@ hipError_t f3d_launch_code_masks(const uint8_t* src, uint8_t* dst, int nviews, i
     return f3d_launch_code_planes(src, dst, nviews, h, w, cb, s);
 }
 
+// k_fuse_mid: code book, prefix / vote count / flag per point, open-view masks, the points, the bins
+static size_t mid_lds_bytes(int words_max) {
+    return (size_t)(128 + (F3D_BLOCK + 4) + 2 * F3D_BLOCK) * 4 + (size_t)F3D_BLOCK * 8 + (size_t)3 * F3D_BLOCK * 8 + (size_t)words_max * F3D_BLOCK * 4;
+}
+
+// slots of the first deferred list whose points can be parked (bins + view masks); deferred points beyond them are redone from nothing
+static int64_t fuse_park_slots(int64_t n, int nviews) {
+    if (nviews > 64 || nviews <= 0) return 0;                 // (only the instances of a call with one 64-view group park points)
+    int64_t k = n / 16 + 4096;
+    if (const char* e = getenv("F3D_DEBUG_PARK_SLOTS")) k = atoll(e);   // tests: force the overflow path (deferred points beyond the parked slots)
+    return k < n ? (k < 0 ? 0 : k) : n;
+}
+// 4 counters, two index lists of n entries (fast -> float64 tier -> exact), the view masks and the parked bins of the first list's slots
+size_t f3d_fuse_todo_bytes(int64_t n, int nviews, int nclasses) {
+    const size_t k = (size_t)fuse_park_slots(n, nviews);
+    return 16 + (size_t)n * 8 + k * ((size_t)((nviews + 63) / 64) * 8 + (size_t)((nclasses + 1 + 2 + 3) >> 2) * 4);
+}
+
 template <typename KernelT>
 static hipError_t raise_lds(KernelT kernel, size_t lds) {
     if (lds <= 48 * 1024) return hipSuccess;
@@ -1447,7 +1587,8 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
                                 int h, int w, int nclasses, const f3d_filter_args& flt, double threshold, int64_t* classes, uint16_t* votes,
                                 int* err, const int32_t* perm, bool gather_xyz, unsigned int* todo_count, int32_t* todo,
                                 unsigned int* todo2_count, int32_t* todo2, const f3d_codebook* cb, void* tables, int mode, int grid,
-                                int v0, int v1, uint32_t* carry, void* xyz_keep, hipStream_t s) {
+                                int v0, int v1, uint32_t* carry, void* xyz_keep, unsigned long long* umask, uint32_t* park, int park_slots,
+                                int park_stride, hipStream_t s) {
     // CARRY: the fast kernel runs over the views [v0, v1) only and parks / resumes the vote bins in `carry`; the float64 tier and
     // the exact kernel follow the last chunk (v1 == nviews) and see every view.  Otherwise v0 = 0, v1 = nviews.
     const bool fast = cmasks != nullptr;                     // no coded masks (nclasses > F3D_CODE_MAX_NCLASSES): exact kernel only
@@ -1488,35 +1629,37 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
         // knows how many labels the masks contain -- the code book says which instance runs, the others return at once
         const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2, one_group);
         hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
-                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
+                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
         if (nclasses + 3 > F3D_BIN32_MAX_CODES)
             hipLaunchKernelGGL(km2, g, b, lds_mid, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
                                classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS,
-                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
         if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS)
             hipLaunchKernelGGL(km3, g, b, lds_large, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
                                classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 4 * F3D_PACKED_LARGE_WORDS,
-                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
         if (nclasses + 3 > 4 * F3D_PACKED_LARGE_WORDS) {
             hipLaunchKernelGGL(kf, g, b, lds_full, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev,
                                threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_LARGE_WORDS + 1, 256,
-                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep);
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
         }
         if (chunk_flags & 2) return hipGetLastError();       // more view chunks to come
         // middle tier: the deferred points again, in float64; what it cannot prove either lands in the second list
         auto km = k_fuse_mid<T, V>;
-        const size_t lds_tier2 = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
+        const size_t lds_tier2 = mid_lds_bytes(words_max);
         if ((e = raise_lds(km, lds_tier2)) != hipSuccess) return e;
         hipLaunchKernelGGL(km, dim3(1024), b, lds_tier2, s, (const T*)xyz, todo_count, todo, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
-                           flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo2_count, todo2, cb);
+                           flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo2_count, todo2, cb,
+                           (const unsigned long long*)umask, (const uint32_t*)park, park_slots, park_stride);
     }
     if (fast && !masks) {                                    // only coded planes exist (f3d_fuse_chunk_coded_dev): reference arithmetic on them
         if (V || nviews > 255) return hipErrorInvalidValue;
         auto kx = k_fuse_mid<T, false, true>;
-        const size_t lds_tier3 = (128 + (size_t)words_max * F3D_BLOCK) * sizeof(uint32_t);
+        const size_t lds_tier3 = mid_lds_bytes(words_max);
         if ((e = raise_lds(kx, lds_tier3)) != hipSuccess) return e;
         hipLaunchKernelGGL(kx, dim3(512), b, lds_tier3, s, (const T*)xyz, todo2_count, todo2, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
-                           flt.cls_dev, threshold, classes, (uint16_t*)nullptr, err, perm, gather_xyz ? 1 : 0, (unsigned int*)nullptr, (int32_t*)nullptr, cb);
+                           flt.cls_dev, threshold, classes, (uint16_t*)nullptr, err, perm, gather_xyz ? 1 : 0, (unsigned int*)nullptr, (int32_t*)nullptr, cb,
+                           (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0, 0);
         return hipGetLastError();
     }
     if (mode == MODE_HIST8) {
@@ -1563,6 +1706,10 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     if (n <= 0) return hipSuccess;
     unsigned int* todo2_count = todo_count + 1;
     int32_t* todo2 = todo + n;
+    // behind the two lists (f3d_fuse_todo_bytes): per slot of the first list the masks of the views still to be decided, then the parked bins
+    const int park_slots = (int)fuse_park_slots(n, nviews), park_stride = (nclasses + 1 + 2 + 3) >> 2, ngroups = (nviews + 63) / 64;
+    unsigned long long* umask = reinterpret_cast<unsigned long long*>(todo + 2 * n);
+    uint32_t* park = reinterpret_cast<uint32_t*>(umask + (size_t)park_slots * ngroups);
     const int mode = f3d_fuse_pick_mode(nviews, flt.nfilter, votes != nullptr);      // bins of the exact kernel; the fast one uses 8 bits
     const int64_t ntiles = (n + F3D_BLOCK * 2 - 1) / (F3D_BLOCK * 2);          // k_fuse: 2 points per lane
     int grid = (int)(ntiles < F3D_FUSE_GRID ? ntiles : F3D_FUSE_GRID);
@@ -1570,7 +1717,7 @@ hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view
     if (carry && votes) return hipErrorInvalidValue;
     if (!carry) { v0 = 0; v1 = nviews; }
     // (with coded masks the counters of the deferred lists were zeroed by f3d_launch_fuse_setup, which must precede this call)
-#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, v0, v1, carry, xyz_keep, s
+#define F3D_ARGS xyz, n, views_dev, nviews, masks, cmasks, h, w, nclasses, flt, threshold, classes, votes, err, perm, gather_xyz, todo_count, todo, todo2_count, todo2, cb, tables, mode, grid, v0, v1, carry, xyz_keep, umask, park, park_slots, park_stride, s
     if (carry) return dtype == F3D_F64 ? launch_fuse_t<double, false, true>(F3D_ARGS) : launch_fuse_t<float, false, true>(F3D_ARGS);
     if (dtype == F3D_F64) return votes ? launch_fuse_t<double, true, false>(F3D_ARGS) : launch_fuse_t<double, false, false>(F3D_ARGS);
     return votes ? launch_fuse_t<float, true, false>(F3D_ARGS) : launch_fuse_t<float, false, false>(F3D_ARGS);

@@ -67,6 +67,7 @@ int f3d_fuse_pick_mode(int nviews, int nfilter, bool want_votes);
 // (read by the exact kernel); cmasks: their coded, tiled copy made by f3d_launch_code_masks (read by the fast kernel),
 // or NULL when nclasses > F3D_CODE_MAX_NCLASSES -- the exact kernel then labels every point.
 #define F3D_CODE_MAX_NCLASSES 253            // labels 0..nclasses + "rejected" + "no sample" must fit the 256 byte codes
+size_t f3d_fuse_todo_bytes(int64_t n, int nviews, int nclasses);   // the todo_count / todo scratch of f3d_launch_fuse (counters, lists, parked bins)
 hipError_t f3d_launch_fuse(const void* xyz, int dtype, int64_t n, const f3d_view* views_dev, int nviews,
                            const uint8_t* masks, const uint8_t* cmasks, int h, int w, int nclasses, const f3d_filter_args& flt,
                            double threshold, int64_t* classes, uint16_t* votes, int* err, const int32_t* perm, bool gather_xyz,

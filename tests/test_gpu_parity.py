@@ -343,6 +343,36 @@ def test_device_api_sort_flags_and_prepared_layout(ctx):
                           O.forward_votes(sc['points'], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth']))
 
 
+@pytest.mark.parametrize('mask_kind', ['block64', 'iid'])
+def test_partially_deferred_points_parked_bins_and_their_overflow(ctx, mask_kind, monkeypatch):
+    """A point the float32 kernel cannot finish keeps the votes of its proven views: bins parked in HBM, one mask of open views, the
+    float64 tier visits those views only (calls with at most 64 views).  Deferred points beyond the parked slots (n/16 + 4096 of them) are
+    redone from nothing -- forced here through F3D_DEBUG_PARK_SLOTS; an unsorted cloud (whole-scene wave boxes, wide float32 bounds)
+    makes the deferred list long.  Labels and vote rows must not depend on which way a point went."""
+    sc = synth.scene('C3', n=120_000, mask_kind=mask_kind)
+    views = f3d.views_build(sc['K'], sc['w'], sc['h'], sc['wxyzs'], sc['translations'], sc['max_depth'])
+    sel = np.arange(0, 120_000, 7)
+    want, want_votes = O.project_vote_argmax(sc['points'][sel], sc['K'], sc['wxyzs'], sc['translations'], sc['masks'], sc['max_depth'],
+                                             133, 0.0, None, return_votes=True)
+    runs = {}
+    for slots, flags in ((None, 0), (None, f3d.FUSE_SORT), ('100', 0), ('0', 0), ('100', f3d.FUSE_SORT)):
+        if slots is None:
+            monkeypatch.delenv('F3D_DEBUG_PARK_SLOTS', raising=False)
+        else:
+            monkeypatch.setenv('F3D_DEBUG_PARK_SLOTS', slots)
+        cls, rows = _dev_fuse(ctx, sc['points'], views, sc['masks'], None, 0.0, flags, votes_at=sel)
+        deferred = ctx.fuse_deferred()
+        runs[(slots, flags)] = (cls, deferred)
+        assert np.array_equal(cls[sel], want), (slots, flags)
+        assert np.array_equal(rows.astype(np.float64), want_votes), (slots, flags)
+    monkeypatch.delenv('F3D_DEBUG_PARK_SLOTS', raising=False)
+    ref = runs[(None, 0)][0]
+    for key, (cls, deferred) in runs.items():
+        assert np.array_equal(cls, ref), key
+    assert runs[('100', 0)][1][0] > 1000 and runs[(None, 0)][1][0] == runs[('100', 0)][1][0]     # the overflow path really ran
+    assert (want != 133).mean() > 0.5
+
+
 def test_general_K_matches(ctx):
     sc = synth.scene('C1', n=20000)
     K = np.array([[410.5, 1.75, 250.25], [0.125, 395.0, 260.5], [0., 0., 1.]])
