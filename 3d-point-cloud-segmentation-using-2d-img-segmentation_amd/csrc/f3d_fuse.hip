@@ -24,6 +24,7 @@
 #pragma clang fp contract(off)
 
 #define F3D_BLOCK 256
+#define F3D_PART_MAX_GROUPS 16            // view groups whose open-view masks a parked point carries (more: the point is redone from nothing)
 #ifndef F3D_NT_CLASSES
 #define F3D_NT_CLASSES 1                 // the (scattered) label stores carry the non-temporal hint (measured: -2.5 % of the step)
 #endif
@@ -852,17 +853,16 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             if (!act[0]) { DX.x = __builtin_nanf(""); }
             if (!act[1]) { DX.y = __builtin_nanf(""); }
         }
-        // PART (the instances of a call with at most 64 views, not view-chunked): a point with unproven decisions keeps the votes of its
-        // proven views.  um = the views that left one of the point's decisions unproven; at the end the point's bins are parked in
-        // park[slot] next to that mask, and the float64 tier visits the marked views only (typically one of 64).  Points without usable
-        // float32 coordinates, points beyond park_slots deferred ones, and every deferred point of the other instances are redone from
-        // nothing (sign bit of the list entry).
-        // (The dword-bin instance of a call with several view groups keeps the plain flag: the masks would cost it its fourth wave per SIMD;
-        // the other instances track the mask and use it when the call has one group.)
-        constexpr bool PART = !CARRY && !WRAP && (TLDS || !BIN32);
-        const bool part1 = PART && ngroups == 1;
+        // PART (every call that is not view-chunked): a point with unproven decisions keeps the votes of its proven views.  um = the views of
+        // the current 64-view group that left one of the point's decisions unproven.  At the end of a group a point with such views takes its
+        // slot in the deferred list (once) and leaves the group's mask in umask[slot][group]; at the end its bins are parked in park[slot],
+        // and the float64 tier visits the marked views only (typically one of all).  Points without usable float32 coordinates, with a
+        // bin beyond 255, beyond park_slots deferred ones or F3D_PART_MAX_GROUPS view groups are redone from nothing (sign bit of the list entry).
+        constexpr bool PART = !CARRY;
+        const bool part_rt = PART && park_slots > 0 && ngroups <= F3D_PART_MAX_GROUPS;
         unsigned long long um[2] = {0ull, 0ull};             // PART
-        unsigned unsure[2] = {0u, 0u};                       // !PART: a visible view left one of the point's decisions unproven
+        int slot[2] = {-1, -1};                              // PART: the point's place in the deferred list, taken at its first unproven view
+        unsigned unsure[2] = {0u, 0u};                       // !PART (or no room for masks): a visible view left one of the point's decisions unproven
         if (CARRY && (chunk_flags & 1)) {                                   // the bins (and the deferred flag) of the earlier view chunks
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
@@ -1064,9 +1064,10 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     for (int q = 0; q < PPL; ++q) unsv[q] = maybe[q];                         // the box comes too close to this view's camera plane
                 }
                 if (PART) {
-                    if (__any(unsv[0] | unsv[1])) {                            // rare
+                    // (act: with no plane to test -- a box entirely inside the view -- a lane without a usable point is "inside" and never "safe")
+                    if (__any((unsv[0] & act[0]) | (unsv[1] & act[1]))) {      // rare
 #pragma unroll
-                        for (int q = 0; q < PPL; ++q) um[q] |= unsv[q] ? (1ull << bit) : 0ull;
+                        for (int q = 0; q < PPL; ++q) um[q] |= (unsv[q] & act[q]) ? (1ull << bit) : 0ull;
                     }
                 } else {
 #pragma unroll
@@ -1079,12 +1080,27 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 vote(0, pend[0]); vote(1, pend[1]);
                 pend[0] = gather(off[0]); if (PPL == 2) pend[1] = gather(off[1]);
             }
+            // end of the group: the points with unproven views leave the group's mask behind (rare)
+            if (PART && __any(((um[0] | um[1]) != 0ull) | (slot[0] >= 0) | (slot[1] >= 0))) {
+#pragma unroll
+                for (int q = 0; q < PPL; ++q) {
+                    if (!part_rt) { unsure[q] = um[q] != 0ull ? 1u : unsure[q]; }
+                    else if (act[q] && (um[q] != 0ull || slot[q] >= 0)) {         // (act: only a usable point ever takes a slot)
+                        if (slot[q] < 0) {
+                            slot[q] = (int)atomicAdd(todo_count, 1u);
+                            if (slot[q] < park_slots) for (int gg = 0; gg < g; ++gg) umask[(size_t)slot[q] * ngroups + gg] = 0ull;
+                        }
+                        if (slot[q] < park_slots) umask[(size_t)slot[q] * ngroups + g] = um[q];
+                    }
+                    um[q] = 0ull;
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             vote(q, pend[q]);
-            const bool part = act[q] & (PART ? um[q] != 0ull : unsure[q] != 0u);   // unproven views: the float64 tier adds their votes to the parked bins
-            bool full = defer[q] | (part & !part1);            // ... or redoes the point from nothing
+            const bool part = act[q] & ((PART && slot[q] >= 0) | (unsure[q] != 0u));   // unproven views: the float64 tier adds their votes to the parked bins
+            bool full = defer[q] | (part & !part_rt);          // ... or redoes the point from nothing
             defer[q] = defer[q] | part;
             uint32_t* hc = q ? hcol1 : hcol0;
             if (CARRY && (chunk_flags & 2)) {                                 // more views to come: park the bins in HBM
@@ -1109,11 +1125,12 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
             full = full | (live[q] & !trusted);
             const bool d = defer[q] | full;
             if (d) {
-                const int sl = (int)atomicAdd(todo_count, 1u);
-                full = full | !part1 | (sl >= park_slots);
+                const int sl = (PART && slot[q] >= 0) ? slot[q] : (int)atomicAdd(todo_count, 1u);
+                full = full | !part_rt | (sl >= park_slots) | !(PART && slot[q] >= 0);
+                if (BIN32 && !full && nviews > 255)                           // (a dword bin beyond 255 does not fit the parked byte)
+                    for (int c = 1; c < ncodes; ++c) full = full | (hc[c * F3D_BLOCK] > 255u);
                 todo[sl] = (gather_xyz ? orig[q] : (i0 + 64 * q)) | (full ? (int)0x80000000 : 0);   // index into xyz as this launch sees it
                 if (PART && !full) {                                          // the bins, four 8-bit counts to a dword as the other tiers hold them
-                    umask[sl] = um[q];
                     uint32_t* pk = park + (size_t)sl * park_stride;
                     for (int wd = 0; wd < words; ++wd) {
                         uint32_t x = 0u;
@@ -1220,6 +1237,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
         const int entry = live ? in_list[k] : 0;
         const int src = entry & 0x7fffffff;                                       // index into xyz as k_fuse saw it
         const bool full = EXACT | (entry < 0) | (k >= park_slots) | (umask == nullptr);
+#ifdef F3D_DEBUG_MID
+        if (live) printf("mid: k %d entry %x full %d count %d park_slots %d ngroups %d words %d\n", k, entry, (int)full, count, park_slots, ngroups, words);
+#endif
         {
             f3d_p3 p = {0.0, 0.0, 0.0};
             if (live) p = load_point(xyz, (int64_t)src);
@@ -1273,6 +1293,9 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
                 unsigned long long mm = smask[lo];
                 for (unsigned r = j - spre[lo]; r > 0; --r) mm &= mm - 1ull;
                 const int v = 64 * g + __builtin_ctzll(mm);
+#ifdef F3D_DEBUG_MID
+                if (v >= nviews || mm == 0ull) { printf("mid: blk %d tid %d j %u total %u lo %d spre %u mask %llx mm %llx v %d count %d exact %d\n", (int)blockIdx.x, tid, j, total, lo, spre[lo], smask[lo], mm, v, count, (int)EXACT); continue; }
+#endif
                 const f3d_p3 p = {spt[lo], spt[F3D_BLOCK + lo], spt[2 * F3D_BLOCK + lo]};
                 const f3d_view& vw = views[v];
                 bool hit = false, defer = false;
@@ -1315,7 +1338,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
         const bool trusted = finish_coded<WRITE_VOTES, true>(snv[tid], hist + tid, words, lut, inv, nfilter, fcls, nclasses, threshold,
                                                              live & !defer, orig, classes, votes_out, bad);
         defer = defer | (live & !trusted);
-        if (!EXACT && defer) out_list[atomicAdd(out_count, 1u)] = src;
+        if (defer && out_list) out_list[atomicAdd(out_count, 1u)] = src;  // (EXACT: only a point with a wrapped 8-bit bin, more than 255 views)
         if (bad & !defer) atomicOr(err, F3D_DEVERR_FUSE);
         __syncthreads();                                                  // (the next round overwrites the bins)
     }
@@ -1565,7 +1588,7 @@ static size_t mid_lds_bytes(int words_max) {
 
 // slots of the first deferred list whose points can be parked (bins + view masks); deferred points beyond them are redone from nothing
 static int64_t fuse_park_slots(int64_t n, int nviews) {
-    if (nviews > 64 || nviews <= 0) return 0;                 // (only the instances of a call with one 64-view group park points)
+    if (nviews > 64 * F3D_PART_MAX_GROUPS || nviews <= 0) return 0;
     int64_t k = n / 16 + 4096;
     if (const char* e = getenv("F3D_DEBUG_PARK_SLOTS")) k = atoll(e);   // tests: force the overflow path (deferred points beyond the parked slots)
     return k < n ? (k < 0 ? 0 : k) : n;
@@ -1652,25 +1675,33 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
                            flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo2_count, todo2, cb,
                            (const unsigned long long*)umask, (const uint32_t*)park, park_slots, park_stride);
     }
-    if (fast && !masks) {                                    // only coded planes exist (f3d_fuse_chunk_coded_dev): reference arithmetic on them
-        if (V || nviews > 255) return hipErrorInvalidValue;
-        auto kx = k_fuse_mid<T, false, true>;
+    const unsigned int* exact_count = todo2_count;           // the list k_fuse_exact works on (NULL list: every point)
+    const int32_t* exact_list = fast ? todo2 : nullptr;
+    if (fast) {
+        // last tier on the coded planes: the reference's arithmetic (exact 5-plane test, canonical projection, IEEE divisions), the
+        // (point, view) pairs dealt over the block like the float64 tier's -- one thread walking all views of one of a handful of points
+        // took 0.38 ms for TWO points x 256 views.  Up to 255 views nothing is left afterwards; beyond, a point whose 8-bit bin wrapped
+        // goes on to k_fuse_exact (16-bit bins, raw masks) through a third list that reuses the first list's storage.
+        const bool wide = nviews > 255;
+        if (wide && !masks) return hipErrorInvalidValue;     // (only coded planes: f3d_fuse_chunk_coded_dev, at most 255 views)
+        auto kx = k_fuse_mid<T, V, true>;
         const size_t lds_tier3 = mid_lds_bytes(words_max);
         if ((e = raise_lds(kx, lds_tier3)) != hipSuccess) return e;
         hipLaunchKernelGGL(kx, dim3(512), b, lds_tier3, s, (const T*)xyz, todo2_count, todo2, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
-                           flt.cls_dev, threshold, classes, (uint16_t*)nullptr, err, perm, gather_xyz ? 1 : 0, (unsigned int*)nullptr, (int32_t*)nullptr, cb,
-                           (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0, 0);
-        return hipGetLastError();
+                           flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, wide ? todo_count + 2 : (unsigned int*)nullptr,
+                           wide ? todo : (int32_t*)nullptr, cb, (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0, 0);
+        if (!wide) return hipGetLastError();
+        exact_count = todo_count + 2; exact_list = todo;
     }
     if (mode == MODE_HIST8) {
         auto ke = k_fuse_exact<T, MODE_HIST8, V>;
         if ((e = raise_lds(ke, lds_exact)) != hipSuccess) return e;
-        hipLaunchKernelGGL(ke, ge, b, lds_exact, s, (const T*)xyz, n, todo2_count, fast ? todo2 : nullptr, views_dev, nviews, masks, h, w, nclasses,
+        hipLaunchKernelGGL(ke, ge, b, lds_exact, s, (const T*)xyz, n, exact_count, exact_list, views_dev, nviews, masks, h, w, nclasses,
                            flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0);
     } else {
         auto ke = k_fuse_exact<T, MODE_HIST16, V>;
         if ((e = raise_lds(ke, lds_exact)) != hipSuccess) return e;
-        hipLaunchKernelGGL(ke, ge, b, lds_exact, s, (const T*)xyz, n, todo2_count, fast ? todo2 : nullptr, views_dev, nviews, masks, h, w, nclasses,
+        hipLaunchKernelGGL(ke, ge, b, lds_exact, s, (const T*)xyz, n, exact_count, exact_list, views_dev, nviews, masks, h, w, nclasses,
                            flt, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0);
     }
     return hipGetLastError();
