@@ -951,7 +951,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #endif
             while (todo_v) {
                 int cbit[F3D_CHUNK]; unsigned coff[2][F3D_CHUNK];
-                bool use[F3D_CHUNK], uns[2][F3D_CHUNK];
+                bool use[F3D_CHUNK];
+                unsigned long long unsm[2][F3D_CHUNK];                         // PART: the lanes a view left unproven, as a (scalar) lane mask
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) {
                     use[k] = todo_v != 0ull;
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                     project_offset2(r, DX, DY, DZ, fi0, fi1, safe);
 #pragma unroll
                     for (int q = 0; q < PPL; ++q) {
-                        if (PART) uns[q][k] = act[q] & !safe[q];               // (an unused slot repeats a row of this chunk: same answer)
+                        if (PART) unsm[q][k] = __ballot(act[q] & !safe[q]);    // (an unused slot repeats a row of this chunk: same answer)
                         else unsure[q] = safe[q] ? unsure[q] : 1u;
                         const unsigned o = r.obase + rel_offset(fi0[q], fi1[q], c_row);   // computed for every lane: a select, not a branch
                         coff[q][k] = (safe[q] & use[k]) ? o : 0u;              // offset 0: a border tile, "no sample"
@@ -988,15 +989,17 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 #endif
 #pragma unroll
                 for (int k = 0; k < F3D_CHUNK; ++k) { ccode[0][k] = gather(coff[0][k]); if (PPL == 2) ccode[1][k] = gather(coff[1][k]); }
-                if (PART) {                                                    // rare: a lane mask test (scalar) in the common case
-                    bool au = false;
+                if (PART) {                                                    // scalar in the common case: OR of the lane masks, one branch
+                    unsigned long long au = 0ull;
 #pragma unroll
-                    for (int k = 0; k < F3D_CHUNK; ++k) au = au | uns[0][k] | (PPL == 2 ? uns[1][k] : false);
-                    if (__any(au)) {
+                    for (int k = 0; k < F3D_CHUNK; ++k) au |= unsm[0][k] | (PPL == 2 ? unsm[1][k] : 0ull);
+                    if (__builtin_expect(au != 0ull, 0)) {                     // rare
+                        asm volatile("" ::: "memory");                         // (keeps the compiler from flattening this branch into the loop body: +34 VALU per chunk)
+                        const unsigned long long me = 1ull << lane;
 #pragma unroll
                         for (int k = 0; k < F3D_CHUNK; ++k)
 #pragma unroll
-                            for (int q = 0; q < PPL; ++q) um[q] |= uns[q][k] ? (1ull << cbit[k]) : 0ull;
+                            for (int q = 0; q < PPL; ++q) um[q] |= (unsm[q][k] & me) ? (1ull << cbit[k]) : 0ull;
                     }
                 }
             }
@@ -1065,9 +1068,12 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 }
                 if (PART) {
                     // (act: with no plane to test -- a box entirely inside the view -- a lane without a usable point is "inside" and never "safe")
-                    if (__any((unsv[0] & act[0]) | (unsv[1] & act[1]))) {      // rare
-#pragma unroll
-                        for (int q = 0; q < PPL; ++q) um[q] |= (unsv[q] & act[q]) ? (1ull << bit) : 0ull;
+                    const unsigned long long u0 = __ballot(unsv[0] & act[0]), u1 = __ballot(unsv[1] & act[1]);
+                    if (__builtin_expect((u0 | u1) != 0ull, 0)) {              // rare
+                        asm volatile("" ::: "memory");                         // (as above)
+                        const unsigned long long me = 1ull << lane;
+                        um[0] |= (u0 & me) ? (1ull << bit) : 0ull;
+                        if (PPL == 2) um[1] |= (u1 & me) ? (1ull << bit) : 0ull;
                     }
                 } else {
 #pragma unroll

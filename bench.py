@@ -293,6 +293,25 @@ def variants_leg(torch, ctx, dev, stream, xyz, dtype, n, views, V, S, flags, per
         out[name] = dict(ms_per_step=round(tk * 1e3, 4), points_per_s=round(n / tk, 1), labels_in_masks=int(len(np.unique(m[:4].cpu().numpy()))),
                          filter_classes=flt)
         del m
+    # the C5 shape of the fused call on this cloud: 256 views (four 64-view groups: the instances that read their view tables from global
+    # memory; deferred points carry one mask of open views per group)
+    import f3d
+    V5 = 256
+    K = np.array([[800., 0, S / 2], [0, 800., S / 2], [0, 0, 1]])
+    q5, t5 = synth.ring_views(V5)
+    v5 = torch.from_numpy(f3d.views_build(K, S, S, q5, t5, 10.0)).to(dev)
+    m5 = torch.from_numpy(synth.masks(V5, S, S, 'block64')).to(dev)
+
+    def fn5():
+        ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, v5.data_ptr(), V5, m5.data_ptr(), S, S, 133, 0.5, None,
+                                    classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
+    tk = time_kernel(torch, fn5, 3, stream)
+    ctx.take_device_error(stream.cuda_stream)
+    d5 = ctx.fuse_deferred(stream.cuda_stream)
+    out['block64_256_views'] = dict(ms_per_step=round(tk * 1e3, 4), points_per_s=round(n / tk, 1), point_views_per_s=round(n * V5 / tk, 1),
+                                    labels_in_masks=int(len(np.unique(m5[:4].cpu().numpy()))), filter_classes=None,
+                                    deferred_points=dict(to_float64_tier=d5[0], to_exact_arithmetic=d5[1]))
+    del m5, v5
     return out
 
 
