@@ -322,6 +322,8 @@ class _MergeState:
         self.cands = {k: v[0] for k, v in self.members.items()} if self.members is not None else {}
         self.prof['group'] = time.perf_counter() - t0
         self.boxes, self.failed = {}, {}
+        self.parents = None                               # merge_bb's mirror of [e["parent_id"] for e in info_sem] (vectorised partner search)
+        self.cnt = self.lo = self.hi = self.have = None
         done = False
         if ids_ok and self.gpu_fit and hasattr(self.cloud, 'candidates_and_boxes'):
             t0 = time.perf_counter()
@@ -397,6 +399,29 @@ class _MergeState:
     def count(self, i):
         return self.counts.get(int(i), 0)
 
+    def mirror(self, info_sem, nlist):
+        """Array form of what check_intersection_open3d's partner loop reads per id2 (parent_id of the CURRENT list entry, member count,
+        bounds of the fitted box): merge_bb keeps it in step with its deletions and relabels, so that the loop over id2 becomes array
+        operations.  The loop's decisions (order, the early return at a small instance, the list-index quirks) are unchanged."""
+        size = max(nlist, (max(self.counts) + 1) if self.counts else 0, 1)
+        try:
+            self.parents = np.array([e["parent_id"] for e in info_sem])
+        except Exception:                                 # (ragged / unhashable parent ids: the literal loop handles whatever == means for them)
+            self.parents = None
+        if self.parents is None or self.parents.ndim != 1 or len(self.parents) != len(info_sem):
+            self.parents = None
+            return
+        self.cnt = np.zeros(size, np.int64)
+        for k, c in self.counts.items():
+            if 0 <= k < size:
+                self.cnt[k] = c
+        self.lo, self.hi = np.zeros((size, 3)), np.zeros((size, 3))
+        self.have = np.zeros(size, bool)
+
+    def drop_info(self, b):
+        if self.parents is not None:
+            self.parents = np.delete(self.parents, b)
+
     def _fit(self, i):
         t0 = time.perf_counter()
         fitted = None
@@ -468,6 +493,11 @@ class _MergeState:
                 self.ids[part] = dst
             self.members.setdefault(dst, []).extend(moved)
         self.counts[dst] = self.counts.get(dst, 0) + self.counts.pop(src, 0)
+        if self.cnt is not None:
+            if 0 <= dst < len(self.cnt):
+                self.cnt[dst] = self.counts[dst]; self.have[dst] = False
+            if 0 <= src < len(self.cnt):
+                self.cnt[src] = 0; self.have[src] = False
         cs = self.cands.pop(src)
         self.cands[dst] = np.sort(np.concatenate([self.cands[dst], cs])) if dst in self.cands else cs   # hull(A u B) has its vertices among both lists
         self.boxes.pop(dst, None); self.boxes.pop(src, None)
@@ -501,14 +531,31 @@ def check_intersection_open3d(id1, id_list, id_info_per_point, pcd_points, pcd, 
         return []
     box1 = st.box(id1)
     cand = []
-    for id2 in range(1, len(id_list)):
-        if id1 != id2 and id2 < len(info_sem) - 1 and id1 < len(info_sem) - 1:
-            if info_sem[id1]["parent_id"] == info_sem[id2]["parent_id"]:
-                if st.count(id2) < 4:
-                    break                                  # the reference returns what it has so far (:83-84)
+    if st.parents is not None and len(st.parents) == len(info_sem) and len(id_list) <= len(st.cnt):
+        # the loop below on arrays (merge_bb's mirror): same-parent partners in ascending order, cut at the first small one
+        L = len(info_sem)
+        if id1 < L - 1:
+            hi = min(len(id_list), L - 1)
+            same = np.flatnonzero(st.parents[1:hi] == st.parents[id1]) + 1
+            same = same[same != id1]
+            small = np.flatnonzero(st.cnt[same] < 4)
+            if small.size:
+                same = same[:small[0]]                     # the reference returns what it has so far (:83-84)
+            for id2 in same[~st.have[same]].tolist():      # boxes fitted (or refitted after a merge) since they were last looked at
                 b2 = st.box(id2)
-                if (box1[3] <= b2[4]).all() and (b2[3] <= box1[4]).all():
-                    cand.append(id2)
+                st.lo[id2], st.hi[id2], st.have[id2] = b2[3], b2[4], True
+            with np.errstate(invalid='ignore'):
+                touch = (box1[3] <= st.hi[same]).all(axis=1) & (st.lo[same] <= box1[4]).all(axis=1)
+            cand = same[touch].tolist()
+    else:
+        for id2 in range(1, len(id_list)):
+            if id1 != id2 and id2 < len(info_sem) - 1 and id1 < len(info_sem) - 1:
+                if info_sem[id1]["parent_id"] == info_sem[id2]["parent_id"]:
+                    if st.count(id2) < 4:
+                        break                              # the reference returns what it has so far (:83-84)
+                    b2 = st.box(id2)
+                    if (box1[3] <= b2[4]).all() and (b2[3] <= box1[4]).all():
+                        cand.append(id2)
     if not cand:
         return []
     hit = st.shares_point(box1, [st.box(c) for c in cand])
@@ -528,6 +575,7 @@ def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=None, dist=None,
     t0 = time.perf_counter()
     id_list = [info_sem[i]["id"] for i in range(len(info_sem))]
     st = _MergeState(pts, id_info_per_point, box_fn, dist, backend, prefilter)
+    st.mirror(info_sem, len(id_list))
     for id1 in range(1, len(id_list)):
         hits = check_intersection_open3d(id1, id_list, id_info_per_point, pts, pcd, info_sem, box_fn, st)
         if hits:
@@ -537,11 +585,21 @@ def merge_bb(dir_name, info_sem, id_info_per_point, pcd, box_fn=None, dist=None,
             for b in hits:
                 if b < len(info_sem):
                     del info_sem[b]
+                    st.drop_info(b)
+    ks, bx = [], []
     for k in range(1, len(info_sem)):
         i = info_sem[k]["id"]
         if st.count(i) > 4:
-            c, R, e = st.box(i)[:3]
-            info_sem[k]["bbox"] = obb_corners(c, R, e).tolist()
+            ks.append(k); bx.append(st.box(i)[:3])
+    if ks:                                                 # obb_corners for all of them at once (the same operations in the same order per element)
+        C = np.array([b[0] for b in bx], np.float64)
+        Rm = np.array([np.asarray(b[1], np.float64) for b in bx]).reshape(-1, 3, 3)
+        E = np.array([b[2] for b in bx], np.float64)
+        x, y, z = (Rm[:, :, a] * E[:, a:a + 1] / 2 for a in range(3))
+        corners = np.stack([C - x - y - z, C + x - y - z, C - x + y - z, C - x - y + z,
+                            C + x + y + z, C - x + y + z, C + x - y + z, C + x + y - z], axis=1)
+        for k, cs in zip(ks, corners.tolist()):
+            info_sem[k]["bbox"] = cs
     print(f'Time taken for merging {n0} to {len(info_sem)} Bounding boxes = {time.perf_counter() - t0} seconds')
     if os.environ.get('F3D_MERGE_PROFILE'):
         print('merge_bb breakdown [s]: ' + ', '.join(f'{k}={v:.3f}' if isinstance(v, float) else f'{k}={v}' for k, v in st.prof.items()))

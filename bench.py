@@ -145,13 +145,32 @@ def merge_leg(local):
     try:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):                  # merge_bb prints its wall time like the reference; stdout carries the JSON line only
+            info_h, ids_h = copy.deepcopy(info), ids.copy()            # merge_bb relabels its arguments in place, like the reference
             t0 = time.perf_counter()
-            out_info, _ = M.merge_bb(None, info, ids, pts)
+            out_info, _ = M.merge_bb(None, info_h, ids_h, pts)
             dt = time.perf_counter() - t0
+            del ids_h
     finally:
         M._MergeState.__init__ = keep
     st = prof['state'].prof
-    del pts, ids
+    # the same merge on a RESIDENT cloud (merge_bb_dev: device tensors in, nothing of the cloud or of the ids crosses PCIe)
+    import torch
+    dev = torch.device('cuda', local)
+    dpts, dids = torch.from_numpy(pts).to(dev), torch.from_numpy(ids).to(dev)
+    torch.cuda.synchronize(dev)
+    M._MergeState.__init__ = spy
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            info_d = copy.deepcopy(info)
+            t0 = time.perf_counter()
+            dev_info, dev_ids = M.merge_bb_dev(info_d, dids, dpts)
+            torch.cuda.synchronize(dev)
+            dt_dev = time.perf_counter() - t0
+    finally:
+        M._MergeState.__init__ = keep
+    st_dev = prof['state'].prof
+    dev_same = [(d['id'], d['area']) for d in dev_info] == [(d['id'], d['area']) for d in out_info]
+    del pts, ids, dpts, dids, dev_ids
     Bs, ns = 384, 192_000
     p2, i2, f2 = scene(Bs, ns)
     t0 = time.perf_counter()
@@ -163,6 +182,9 @@ def merge_leg(local):
     return dict(workload=f'C5 merge: {n} points, {B} instances (Gaussian blobs, parent = id mod 8) -> {len(out_info)} entries',
                 seconds=round(dt, 3), points_per_s=round(n / dt, 1),
                 breakdown_s={k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()},
+                resident=dict(seconds=round(dt_dev, 3), points_per_s=round(n / dt_dev, 1), same_entries_as_host_call=bool(dev_same),
+                              breakdown_s={k: (round(v, 3) if isinstance(v, float) else v) for k, v in st_dev.items()},
+                              note='merge_bb_dev: cloud and ids are device tensors before the clock starts'),
                 algorithmic_bytes_per_scan=24 * n,
                 note='host-pointer call: the 1.2 GB cloud is uploaded inside the timed region (breakdown_s.upload); prefilter = extremes, inner hulls, '
                      'strict-inside filter and ordered compaction, all on the device (f3d_obb_candidates_dev); fit = f3d_obb_fit_dev for every instance in one '
