@@ -1243,9 +1243,6 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
         const int entry = live ? in_list[k] : 0;
         const int src = entry & 0x7fffffff;                                       // index into xyz as k_fuse saw it
         const bool full = EXACT | (entry < 0) | (k >= park_slots) | (umask == nullptr);
-#ifdef F3D_DEBUG_MID
-        if (live) printf("mid: k %d entry %x full %d count %d park_slots %d ngroups %d words %d\n", k, entry, (int)full, count, park_slots, ngroups, words);
-#endif
         {
             f3d_p3 p = {0.0, 0.0, 0.0};
             if (live) p = load_point(xyz, (int64_t)src);
@@ -1299,9 +1296,6 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
                 unsigned long long mm = smask[lo];
                 for (unsigned r = j - spre[lo]; r > 0; --r) mm &= mm - 1ull;
                 const int v = 64 * g + __builtin_ctzll(mm);
-#ifdef F3D_DEBUG_MID
-                if (v >= nviews || mm == 0ull) { printf("mid: blk %d tid %d j %u total %u lo %d spre %u mask %llx mm %llx v %d count %d exact %d\n", (int)blockIdx.x, tid, j, total, lo, spre[lo], smask[lo], mm, v, count, (int)EXACT); continue; }
-#endif
                 const f3d_p3 p = {spt[lo], spt[F3D_BLOCK + lo], spt[2 * F3D_BLOCK + lo]};
                 const f3d_view& vw = views[v];
                 bool hit = false, defer = false;
