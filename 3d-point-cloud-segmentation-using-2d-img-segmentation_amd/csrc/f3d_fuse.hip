@@ -25,6 +25,9 @@
 
 #define F3D_BLOCK 256
 #define F3D_PART_MAX_GROUPS 16            // view groups whose open-view masks a parked point carries (more: the point is redone from nothing)
+#ifndef F3D_MID_DENSE
+#define F3D_MID_DENSE 8                  // k_fuse_mid: more open views per point than this on a block's average -> the views run in the outer loop
+#endif
 #ifndef F3D_NT_CLASSES
 #define F3D_NT_CLASSES 1                 // the (scattered) label stores carry the non-temporal hint (measured: -2.5 % of the step)
 #endif
@@ -1289,26 +1292,19 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
             auto cast = [&](int pt, unsigned b) {                             // several threads may vote for one point: LDS atomics
                 if (b != F3D_CODE_NONE) { atomicAdd(&snv[pt], 1u); atomicAdd(&hist[(b >> 2) * F3D_BLOCK + pt], 1u << ((b & 3u) * 8u)); }
             };
-            for (unsigned j = tid; j < total; j += F3D_BLOCK) {
-                int lo = 0;                                                   // the last point whose prefix is <= j (points without open views are skipped by it)
-#pragma unroll
-                for (int step = F3D_BLOCK / 2; step >= 1; step >>= 1) lo += (spre[lo + step] <= j) ? step : 0;
-                unsigned long long mm = smask[lo];
-                for (unsigned r = j - spre[lo]; r > 0; --r) mm &= mm - 1ull;
-                const int v = 64 * g + __builtin_ctzll(mm);
-                const f3d_p3 p = {spt[lo], spt[F3D_BLOCK + lo], spt[2 * F3D_BLOCK + lo]};
-                const f3d_view& vw = views[v];
+            // one (point, view) pair: the decision of this tier, then the gather of the pair's code (voted one pair later)
+            auto pair = [&](int pt, const f3d_p3& p, int v, const f3d_view& vw, bool on) {
                 bool hit = false, defer = false;
                 int iu = 0, iv = 0;
                 if (EXACT) {
-                    if (f3d_inside_view(vw, p)) {
+                    if (on && f3d_inside_view(vw, p)) {
                         double fu, fv;
                         project_exact(vw, p, fu, fv);
                         if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) { hit = true; iu = (int)fu; iv = (int)fv; }   // NaN compares false
                     }
                 } else {
                     const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
-                    const bool small = pscale < 1.0e30;
+                    const bool small = on & (pscale < 1.0e30);
                     bool maybe, sure;
                     cull_point32(load_cull(vw), (float)p.x, (float)p.y, (float)p.z, (float)pscale, small, maybe, sure);
                     bool inside = small & sure;
@@ -1323,11 +1319,33 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
                         hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
                         defer = defer | unsure;
                     }
-                    if (defer) atomicOr(&sdefer[lo], 1u);
+                    if (defer) atomicOr(&sdefer[pt], 1u);
                 }
                 cast(pend_pt, pend_code);
                 pend_code = (cmasks + (size_t)v * plane)[hit ? mask_offset<true>(iu, iv, wt) : none_off];
-                pend_pt = lo;
+                pend_pt = pt;
+            };
+            if (total > (unsigned)F3D_BLOCK * F3D_MID_DENSE) {
+                // DENSE (block-uniform decision): most points want most views -- a view-chunked call, a cloud full of unusable points, more
+                // view groups than masks are kept for.  Every thread keeps its own point and the views run in the outer loop: their records
+                // are wave-uniform again (scalar loads); dealing 64 pairs per point with per-lane records took 242 us where this takes ~50.
+                const f3d_p3 p = {spt[tid], spt[F3D_BLOCK + tid], spt[2 * F3D_BLOCK + tid]};
+                for (int bit = 0; bit < nvg; ++bit) {
+                    const bool on = (m >> bit) & 1ull;
+                    if (!__any(on)) continue;                                     // wave-uniform
+                    pair(tid, p, 64 * g + bit, views[64 * g + bit], on);
+                }
+            } else {
+                for (unsigned j = tid; j < total; j += F3D_BLOCK) {
+                    int lo = 0;                                                   // the last point whose prefix is <= j (points without open views are skipped by it)
+#pragma unroll
+                    for (int step = F3D_BLOCK / 2; step >= 1; step >>= 1) lo += (spre[lo + step] <= j) ? step : 0;
+                    unsigned long long mm = smask[lo];
+                    for (unsigned r = j - spre[lo]; r > 0; --r) mm &= mm - 1ull;
+                    const int v = 64 * g + __builtin_ctzll(mm);
+                    const f3d_p3 p = {spt[lo], spt[F3D_BLOCK + lo], spt[2 * F3D_BLOCK + lo]};
+                    pair(lo, p, v, views[v], true);
+                }
             }
             cast(pend_pt, pend_code);
         }
