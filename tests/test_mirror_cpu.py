@@ -188,3 +188,57 @@ def test_get2dseg_seeds_like_the_reference():
     random.seed(0); np.random.seed(0); torch.manual_seed(0)
     assert a == (random.random(), float(np.random.rand()), float(torch.rand(1)))
     assert torch.backends.cudnn.deterministic is True and torch.backends.cudnn.benchmark is False
+
+
+class _NumpyCloud:
+    """The HIP cloud's interface on a machine without a GPU (grouping by argsort, the oracle's in-box test)."""
+
+    def __init__(self, pts, share):
+        self.pts, (self.lo, self.hi) = pts, share
+
+    def group(self, ids, nids):
+        order = np.argsort(ids, kind='stable').astype(np.int32)
+        return order, np.searchsorted(ids[order], np.arange(nids + 2)).astype(np.int64)
+
+    def cooccurrence(self, packed):
+        mine = self.pts[self.lo:self.hi]
+        m = np.stack([O.points_in_obb(mine, b[0:3], b[3:12].reshape(3, 3), b[12:15]) for b in packed]).astype(np.float32)
+        return ((m @ m.T) > 0).astype(np.uint8)
+
+
+def test_merge_bb_partner_search_on_arrays_keeps_the_reference_control_flow():
+    """merge_bb's partner loop runs on arrays that mirror info_sem (parent of the CURRENT list entry, member counts, box bounds) while
+    entries are deleted and ids relabelled.  Randomised scenes with what the literal loop of merge_intersecting_bb.py:68-91,103-137 is
+    sensitive to -- instances with fewer than 4 points (the early return), empty instances, ids beyond the info list, parents of any
+    hashable type, heavy overlap (many deletions shifting the list under the running index) -- against the oracle's literal restatement."""
+    import copy
+    from Fusion3DSeg.merge_intersecting_bb import merge_bb
+    merged = 0
+    for seed in range(24):
+        rng = np.random.default_rng(seed)
+        nb = int(rng.integers(3, 40))
+        centres = rng.uniform(0, rng.uniform(1.0, 6.0), (nb, 3))
+        sizes = rng.choice([0, 1, 3, 4, 5, 40, 120], nb, p=[0.05, 0.05, 0.1, 0.1, 0.1, 0.3, 0.3])
+        pts = np.vstack([centres[k] + rng.normal(size=(int(sizes[k]), 3)) * rng.uniform(0.05, 0.8, 3) for k in range(nb)] + [np.zeros((0, 3))])
+        ids = np.repeat(np.arange(nb), sizes).astype(np.int64)
+        if len(pts) < 8:
+            continue
+        perm = rng.permutation(len(pts))
+        pts, ids = pts[perm], ids[perm]
+        nparents = int(rng.integers(1, 4))
+        kind = int(rng.integers(3))
+        parent = [(k % nparents) if kind == 0 else str(k % nparents) if kind == 1 else (k % nparents, 'p') for k in range(nb)]
+        if kind == 2:
+            parent = [p[0] * 1.5 for p in parent]                       # floats
+        ninfo = nb if rng.random() < 0.7 else max(2, nb - int(rng.integers(1, 3)))       # ids beyond the info list
+        info = [{'id': k, 'category_id': 86, 'parent_id': parent[k], 'area': int((ids == k).sum())} for k in range(ninfo)]
+        want_info, want_ids = O.merge_bb(copy.deepcopy(info), ids.copy(), pts)
+        got_info, got_ids = merge_bb(None, copy.deepcopy(info), ids.copy(), pts, box_fn=O.obb_from_points, backend=_NumpyCloud)
+        merged += len(info) - len(want_info)
+        assert np.array_equal(got_ids, want_ids), seed
+        assert [(d['id'], d['area']) for d in got_info] == [(d['id'], d['area']) for d in want_info], seed
+        for g, w in zip(got_info, want_info):
+            assert ('bbox' in g) == ('bbox' in w), seed
+            if 'bbox' in w:
+                assert np.array_equal(np.array(g['bbox']), np.array(w['bbox'])), seed
+    assert merged > 40                                                 # the scenes really merge (and delete) a lot
