@@ -4,13 +4,14 @@
 //   k_mask_presence / k_code_lut / k_code_masks : the masks are rewritten once per call into 8x8-pixel tiles of vote-BIN
 //       CODES.  Only labels that occur in the masks (or, with filter_classes, only the filter labels) get a bin, so a
 //       thread's vote histogram is a handful of LDS dwords instead of 34.
-//   k_fuse        : the fast kernel.  One thread owns one point; all per-view arithmetic is FLOAT32: one lane per view
+//   k_fuse        : the fast kernel.  One lane owns two points; all per-view arithmetic is FLOAT32: one lane per view
 //       projects the CENTRE of the wave's bounding box in float64, every lane adds the float32 offset term of its own
-//       point (|p - c| is a few centimetres after the cell sort, so float32 carries the pixel to ~1e-5 px) and accepts
-//       the pixel only when it is farther than a rigorous bound from a pixel border.  A point for which any decision
-//       cannot be proven is appended to a list and recomputed entirely by
-//   k_fuse_exact  : the reference's arithmetic and nothing else (exact 5-plane test, un-normalised quaternion sandwich,
-//       K @ c, IEEE divisions), launched right behind.
+//       points (|p - c| is a few centimetres after the cell sort, so float32 carries the pixel to ~1e-5 px) and accepts
+//       the pixel only when it is farther than a rigorous bound from a pixel border.  A point with a decision that
+//       cannot be proven is appended to a list -- with the votes of its proven views parked and a mask of the open ones --
+//   k_fuse_mid    : float64 on the open (point, view) pairs of that list; what it cannot prove either goes on to
+//   k_fuse_mid<EXACT> / k_fuse_exact : the reference's arithmetic and nothing else (exact 5-plane test, un-normalised
+//       quaternion sandwich, K @ c, IEEE divisions) on the coded planes / on the raw masks, launched right behind.
 // Results are exactly those of the reference arithmetic (oracle order).  No MFMA: nothing here is a dense contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1159,12 +1160,12 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fuse_mid: the middle tier.  One thread per point that k_fuse deferred (2-5 % of a cloud: the float32 bound leaves a
-// band of ~1e-4 px around every pixel border undecided), every view, float64: float32 cull -> float64 FMA refinement ->
-// fast projection h = M (p - t) (9 FMAs, reciprocal + 2 Newton steps), accepted when farther than
-// 2^-43 (|p-t|_1 |r| (mnorm_k + umax mnorm_2) + umax) from a pixel border (> 10x the distance between this and the
-// canonical operation order).  What it still cannot prove (a point within rounding of a plane or of a pixel border: ~1e-3
-// of the cloud) goes on to k_fuse_exact through the second list.  Same coded masks and vote bins as k_fuse.
+// k_fuse_mid: the middle tier, on the points k_fuse deferred (1-5 % of a cloud: the float32 bound leaves a band of ~1e-4 px
+// around every pixel border undecided) and, of those, on the views k_fuse left open.  Per (point, view) pair, float64:
+// float32 cull -> float64 FMA refinement -> fast projection h = M (p - t) (9 FMAs, reciprocal + 2 Newton steps), accepted
+// when farther than 2^-43 (|p-t|_1 |r| (mnorm_k + umax mnorm_2) + umax) from a pixel border (> 10x the distance between
+// this and the canonical operation order).  What it still cannot prove (a point within rounding of a plane or of a pixel
+// border: ~1e-3 of the cloud) goes on to the exact tier through the second list.  Same coded masks and vote bins as k_fuse.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void cull_point64(const f3d_view& vw, f3d_p3 p, double pscale, bool& maybe, bool& sure) {
     const double marg = __builtin_fma(vw.cull_rel64, pscale, vw.cull_abs64);
