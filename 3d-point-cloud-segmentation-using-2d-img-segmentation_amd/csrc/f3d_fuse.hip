@@ -805,7 +805,10 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
     // with the busiest region finished last while others idled -- 0.98 -> 0.85 ms for the fused call at C3, 1.46 -> 1.23 ms with
     // iid masks (profiles/r03_summary.md).  Placement affects speed only, never results.
     int xlog = F3D_XCD_CHUNK_LOG2;                                        // chunk = 2^xlog tiles, smaller for small clouds: at least four chunks per XCD
-    while (xlog > 0 && ntiles < (32 << xlog)) --xlog;
+#ifndef F3D_XCD_MIN_ROWS
+#define F3D_XCD_MIN_ROWS 8               // chunk rows per XCD at least (small clouds: 1.25M points 0.349 -> 0.314 ms per step with 8 instead of 4)
+#endif
+    while (xlog > 0 && ntiles < ((8 * F3D_XCD_MIN_ROWS) << xlog)) --xlog;
     const int chunk_rows = (ntiles + (8 << xlog) - 1) >> (xlog + 3);
     const int tiles_per_xcd = chunk_rows << xlog;                         // positions j of one XCD's list (the last row may hold fewer tiles)
     const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, gx = gridDim.x >> 3;

@@ -180,15 +180,17 @@ __device__ __forceinline__ int64_t rs_item(int64_t tile, int wave, int round, in
 #ifndef F3D_RK_THREADS
 #define F3D_RK_THREADS 256
 #endif
-constexpr int RK_THREADS = F3D_RK_THREADS;
-constexpr int RK_ROUNDS = RS_TILE / RK_THREADS;
-static_assert(RK_THREADS >= 64 && RK_THREADS * RK_ROUNDS == RS_TILE, "the key kernel's block must cover a tile");
-template <typename T>
+// A small cloud (fewer tiles than two per CU) takes 512 threads per tile: the chip is not full either way and the rounds of a thread halve
+// (1.25M points: sort 71 -> 64 us).
+constexpr int RK_SMALL_THREADS = 512;
+template <typename T, int RK_THREADS>
 __global__ __launch_bounds__(RK_THREADS) void k_rs_keys(const T* __restrict__ xyz, int64_t n, const bbox6* __restrict__ partial, int nparts,
                                                          sort_key_t* __restrict__ keys, uint32_t* __restrict__ blkhist, int ntiles) {
     __shared__ uint32_t hist[256];
     __shared__ f3d_cellgrid sg;
     __shared__ uint16_t lut[3][RS_LUT];
+    constexpr int RK_ROUNDS = RS_TILE / RK_THREADS;
+    static_assert(RK_THREADS >= 64 && RK_THREADS * RK_ROUNDS == RS_TILE, "the key kernel's block must cover a tile");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) grid_from_partials(partial, nparts, &sg);
     for (int d = threadIdx.x; d < 256; d += RK_THREADS) hist[d] = 0u;
@@ -433,12 +435,15 @@ hipError_t f3d_launch_cell_sort(const void* xyz, int dtype, int64_t n, void* sor
     const int nparts = (int)(sb < 64 ? sb : 64);                 // (one lane of k_rs_keys' first wave per partial box)
     const int gstream = (int)(gb < 8192 ? gb : 8192);
     const dim3 gt(L.ntiles);
+    const bool small = L.ntiles < 512;                          // fewer tiles than two per CU
     if (dtype == F3D_F64) {
         hipLaunchKernelGGL(k_bbox_partial<double>, dim3(nparts), dim3(SB), 0, s, (const double*)xyz, n, stride, partial);
-        hipLaunchKernelGGL(k_rs_keys<double>, gt, dim3(RK_THREADS), 0, s, (const double*)xyz, n, partial, nparts, keys, hist, L.ntiles);
+        if (small) hipLaunchKernelGGL((k_rs_keys<double, RK_SMALL_THREADS>), gt, dim3(RK_SMALL_THREADS), 0, s, (const double*)xyz, n, partial, nparts, keys, hist, L.ntiles);
+        else hipLaunchKernelGGL((k_rs_keys<double, F3D_RK_THREADS>), gt, dim3(F3D_RK_THREADS), 0, s, (const double*)xyz, n, partial, nparts, keys, hist, L.ntiles);
     } else {
         hipLaunchKernelGGL(k_bbox_partial<float>, dim3(nparts), dim3(SB), 0, s, (const float*)xyz, n, stride, partial);
-        hipLaunchKernelGGL(k_rs_keys<float>, gt, dim3(RK_THREADS), 0, s, (const float*)xyz, n, partial, nparts, keys, hist, L.ntiles);
+        if (small) hipLaunchKernelGGL((k_rs_keys<float, RK_SMALL_THREADS>), gt, dim3(RK_SMALL_THREADS), 0, s, (const float*)xyz, n, partial, nparts, keys, hist, L.ntiles);
+        else hipLaunchKernelGGL((k_rs_keys<float, F3D_RK_THREADS>), gt, dim3(F3D_RK_THREADS), 0, s, (const float*)xyz, n, partial, nparts, keys, hist, L.ntiles);
     }
     hipError_t e = L.wide ? run_passes<uint64_t>(L, base, n, perm, s) : run_passes<uint32_t>(L, base, n, perm, s);
     if (e != hipSuccess) return e;
