@@ -9,9 +9,10 @@
 //       points (|p - c| is a few centimetres after the cell sort, so float32 carries the pixel to ~1e-5 px) and accepts
 //       the pixel only when it is farther than a rigorous bound from a pixel border.  A point with a decision that
 //       cannot be proven is appended to a list -- with the votes of its proven views parked and a mask of the open ones --
-//   k_fuse_mid    : float64 on the open (point, view) pairs of that list; what it cannot prove either goes on to
-//   k_fuse_mid<EXACT> / k_fuse_exact : the reference's arithmetic and nothing else (exact 5-plane test, un-normalised
-//       quaternion sandwich, K @ c, IEEE divisions) on the coded planes / on the raw masks, launched right behind.
+//   k_fuse_mid    : float64 on the open (point, view) pairs of that list; a pair it cannot prove either is decided on the spot by the
+//       reference's arithmetic and nothing else (exact 5-plane test, un-normalised quaternion sandwich, K @ c, IEEE divisions).
+//   k_fuse_exact  : that arithmetic as a kernel of its own over the raw masks: the whole path when no coded masks exist, and the
+//       points whose 8-bit vote bin wrapped (more than 255 views).
 // Results are exactly those of the reference arithmetic (oracle order).  No MFMA: nothing here is a dense contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1204,10 +1205,12 @@ __device__ __forceinline__ bool project_fast(const f3d_view& vw, double umax, f3
     return safe & ((unsigned)iu < (unsigned)W) & ((unsigned)iv < (unsigned)H);
 }
 
-// EXACT: the last tier of a call that only has CODED masks (the planes of the other ranks arrived coded: f3d_fuse_chunk_coded_dev):
-// the reference's arithmetic (exact 5-plane test, canonical projection, IEEE divisions) on the coded planes, bins and segment as
-// in the other tiers; nothing is deferred further.
-template <typename T, bool WRITE_VOTES, bool EXACT = false>
+// A pair this tier cannot prove either (a point within rounding of a plane or of a pixel border, a point without usable float32
+// coordinates) is decided right here by the reference's arithmetic (exact 5-plane test, canonical projection, IEEE divisions) -- the rare
+// branch of `pair` below.  r3 first ran that arithmetic as a launch of its own over a second list (4.7 us when empty, every step).
+// Only a point whose 8-bit bin wrapped (more than 255 views) leaves this kernel unlabelled: out_list -> k_fuse_exact (16-bit bins).
+// diag_count: the number of points that needed the reference's arithmetic (f3d_debug_fuse_deferred).
+template <typename T, bool WRITE_VOTES>
 __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xyz, const unsigned int* __restrict__ in_count, const int32_t* __restrict__ in_list,
                                                          const f3d_view* __restrict__ views, int nviews,
                                                          const uint8_t* __restrict__ cmasks, int H, int W,
@@ -1215,7 +1218,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
                                                          int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out,
                                                          int* __restrict__ err, const int32_t* __restrict__ perm, int gather_xyz,
                                                          unsigned int* __restrict__ out_count, int32_t* __restrict__ out_list,
-                                                         const f3d_codebook* __restrict__ cb,
+                                                         unsigned int* __restrict__ diag_count, const f3d_codebook* __restrict__ cb,
                                                          const unsigned long long* __restrict__ umask, const uint32_t* __restrict__ park,
                                                          int park_slots, int park_stride) {
     // A block takes 256 deferred points at a time.  A point k_fuse parked (list entry without the sign bit, slot < park_slots) comes with
@@ -1229,7 +1232,7 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
     uint32_t* lutw = lds_u32;                                             // lut[256] then inv[256] (bytes)
     uint32_t* spre = lutw + 128;                                          // [F3D_BLOCK + 4] exclusive prefix of the open views per point, wave totals
     uint32_t* snv = spre + F3D_BLOCK + 4;                                 // [F3D_BLOCK] votes cast
-    uint32_t* sdefer = snv + F3D_BLOCK;                                   // [F3D_BLOCK] a decision this tier cannot prove either
+    uint32_t* sdefer = snv + F3D_BLOCK;                                   // [F3D_BLOCK] the point needed the reference's arithmetic (diagnostic)
     unsigned long long* smask = reinterpret_cast<unsigned long long*>(sdefer + F3D_BLOCK);   // [F3D_BLOCK] open views of the current group
     double* spt = reinterpret_cast<double*>(smask + F3D_BLOCK);          // [3][F3D_BLOCK] the points
     uint32_t* hist = reinterpret_cast<uint32_t*>(spt + 3 * F3D_BLOCK);   // [words][F3D_BLOCK]
@@ -1249,13 +1252,12 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
         const bool live = k < count;
         const int entry = live ? in_list[k] : 0;
         const int src = entry & 0x7fffffff;                                       // index into xyz as k_fuse saw it
-        const bool full = EXACT | (entry < 0) | (k >= park_slots) | (umask == nullptr);
+        const bool full = (entry < 0) | (k >= park_slots) | (umask == nullptr);
         {
             f3d_p3 p = {0.0, 0.0, 0.0};
             if (live) p = load_point(xyz, (int64_t)src);
             spt[tid] = p.x; spt[F3D_BLOCK + tid] = p.y; spt[2 * F3D_BLOCK + tid] = p.z;
-            const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
-            sdefer[tid] = (!EXACT && live && !(pscale < 1.0e30)) ? 1u : 0u;
+            sdefer[tid] = 0u;
             unsigned nv0 = 0;
             if (live && !full) {                                                  // the votes of the views k_fuse proved
                 const uint32_t* pk = park + (size_t)k * park_stride;
@@ -1298,32 +1300,33 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
             };
             // one (point, view) pair: the decision of this tier, then the gather of the pair's code (voted one pair later)
             auto pair = [&](int pt, const f3d_p3& p, int v, const f3d_view& vw, bool on) {
-                bool hit = false, defer = false;
+                bool hit = false;
                 int iu = 0, iv = 0;
-                if (EXACT) {
-                    if (on && f3d_inside_view(vw, p)) {
+                const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
+                const bool small = on & (pscale < 1.0e30);
+                bool exact = on & !small;                                         // no usable float32 coordinates
+                bool maybe, sure;
+                cull_point32(load_cull(vw), (float)p.x, (float)p.y, (float)p.z, (float)pscale, small, maybe, sure);
+                bool inside = small & sure;
+                if (small & maybe & !sure) {                                      // inside the float32 margin: decide with float64 FMAs
+                    bool m64, s64;
+                    cull_point64(vw, p, pscale, m64, s64);
+                    inside = s64;
+                    exact = exact | (m64 & !s64);                                 // within rounding of the plane itself
+                }
+                if (inside) {
+                    bool unsure;
+                    hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
+                    exact = exact | unsure;
+                }
+                if (exact) {                                                      // rare: the reference's arithmetic decides this pair
+                    hit = false;
+                    if (f3d_inside_view(vw, p)) {
                         double fu, fv;
                         project_exact(vw, p, fu, fv);
                         if (fu >= 0.0 && fu < (double)W && fv >= 0.0 && fv < (double)H) { hit = true; iu = (int)fu; iv = (int)fv; }   // NaN compares false
                     }
-                } else {
-                    const double pscale = (fabs(p.x) + fabs(p.y)) + fabs(p.z);
-                    const bool small = on & (pscale < 1.0e30);
-                    bool maybe, sure;
-                    cull_point32(load_cull(vw), (float)p.x, (float)p.y, (float)p.z, (float)pscale, small, maybe, sure);
-                    bool inside = small & sure;
-                    if (small & maybe & !sure) {                                  // inside the float32 margin: decide with float64 FMAs
-                        bool m64, s64;
-                        cull_point64(vw, p, pscale, m64, s64);
-                        inside = s64;
-                        defer = m64 & !s64;                                       // within rounding of the plane itself
-                    }
-                    if (inside) {
-                        bool unsure;
-                        hit = project_fast(vw, umax, p, W, H, iu, iv, unsure);
-                        defer = defer | unsure;
-                    }
-                    if (defer) atomicOr(&sdefer[pt], 1u);
+                    atomicOr(&sdefer[pt], 1u);
                 }
                 cast(pend_pt, pend_code);
                 pend_code = (cmasks + (size_t)v * plane)[hit ? mask_offset<true>(iu, iv, wt) : none_off];
@@ -1355,12 +1358,12 @@ __global__ __launch_bounds__(F3D_BLOCK) void k_fuse_mid(const T* __restrict__ xy
         }
         __syncthreads();                                                  // every vote is in
         const int orig = (live && perm && !gather_xyz) ? perm[src] : src;
-        bool defer = sdefer[tid] != 0u;
         bool bad = false;
         const bool trusted = finish_coded<WRITE_VOTES, true>(snv[tid], hist + tid, words, lut, inv, nfilter, fcls, nclasses, threshold,
-                                                             live & !defer, orig, classes, votes_out, bad);
-        defer = defer | (live & !trusted);
-        if (defer && out_list) out_list[atomicAdd(out_count, 1u)] = src;  // (EXACT: only a point with a wrapped 8-bit bin, more than 255 views)
+                                                             live, orig, classes, votes_out, bad);
+        const bool defer = live & !trusted;                               // an 8-bit bin wrapped: more than 255 views
+        if (defer && out_list) out_list[atomicAdd(out_count, 1u)] = src;
+        if (live && diag_count && sdefer[tid] != 0u) atomicAdd(diag_count, 1u);
         if (bad & !defer) atomicOr(err, F3D_DEVERR_FUSE);
         __syncthreads();                                                  // (the next round overwrites the bins)
     }
@@ -1689,32 +1692,21 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
                                ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
         }
         if (chunk_flags & 2) return hipGetLastError();       // more view chunks to come
-        // middle tier: the deferred points again, in float64; what it cannot prove either lands in the second list
+        // float64 tier on the deferred points' open views, the reference's arithmetic for what it cannot prove either.  Beyond 255 views a
+        // point whose 8-bit bin wrapped goes on to k_fuse_exact (16-bit bins, raw masks) through a list in the second list's storage.
+        const bool wide = nviews > 255;
+        if (wide && !masks) return hipErrorInvalidValue;     // (only coded planes: f3d_fuse_chunk_coded_dev, at most 255 views)
         auto km = k_fuse_mid<T, V>;
         const size_t lds_tier2 = mid_lds_bytes(words_max);
         if ((e = raise_lds(km, lds_tier2)) != hipSuccess) return e;
         hipLaunchKernelGGL(km, dim3(1024), b, lds_tier2, s, (const T*)xyz, todo_count, todo, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
-                           flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo2_count, todo2, cb,
-                           (const unsigned long long*)umask, (const uint32_t*)park, park_slots, park_stride);
-    }
-    const unsigned int* exact_count = todo2_count;           // the list k_fuse_exact works on (NULL list: every point)
-    const int32_t* exact_list = fast ? todo2 : nullptr;
-    if (fast) {
-        // last tier on the coded planes: the reference's arithmetic (exact 5-plane test, canonical projection, IEEE divisions), the
-        // (point, view) pairs dealt over the block like the float64 tier's -- one thread walking all views of one of a handful of points
-        // took 0.38 ms for TWO points x 256 views.  Up to 255 views nothing is left afterwards; beyond, a point whose 8-bit bin wrapped
-        // goes on to k_fuse_exact (16-bit bins, raw masks) through a third list that reuses the first list's storage.
-        const bool wide = nviews > 255;
-        if (wide && !masks) return hipErrorInvalidValue;     // (only coded planes: f3d_fuse_chunk_coded_dev, at most 255 views)
-        auto kx = k_fuse_mid<T, V, true>;
-        const size_t lds_tier3 = mid_lds_bytes(words_max);
-        if ((e = raise_lds(kx, lds_tier3)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kx, dim3(512), b, lds_tier3, s, (const T*)xyz, todo2_count, todo2, views_dev, nviews, cmasks, h, w, nclasses, flt.nfilter,
                            flt.cls_dev, threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, wide ? todo_count + 2 : (unsigned int*)nullptr,
-                           wide ? todo : (int32_t*)nullptr, cb, (const unsigned long long*)nullptr, (const uint32_t*)nullptr, 0, 0);
+                           wide ? todo2 : (int32_t*)nullptr, todo2_count, cb,
+                           (const unsigned long long*)umask, (const uint32_t*)park, park_slots, park_stride);
         if (!wide) return hipGetLastError();
-        exact_count = todo_count + 2; exact_list = todo;
     }
+    const unsigned int* exact_count = fast ? todo_count + 2 : todo2_count;   // the list k_fuse_exact works on (NULL list: every point)
+    const int32_t* exact_list = fast ? todo2 : nullptr;
     if (mode == MODE_HIST8) {
         auto ke = k_fuse_exact<T, MODE_HIST8, V>;
         if ((e = raise_lds(ke, lds_exact)) != hipSuccess) return e;
