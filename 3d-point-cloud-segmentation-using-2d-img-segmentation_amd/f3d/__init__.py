@@ -640,7 +640,7 @@ class Context:
         return tuple(int(x) for x in stats)
 
     def fuse_deferred(self, stream=None):
-        """(points the float32 kernel deferred to the float64 tier, points that went on to the exact kernel) of the last fused call."""
+        """(points the float32 kernel deferred to the float64 tier, points of those that needed the reference's own arithmetic) of the last fused call."""
         c = np.zeros(2, np.uint32)
         self._check(self._lib.f3d_debug_fuse_deferred(self._h, stream, _ptr(c)))
         return int(c[0]), int(c[1])

@@ -245,7 +245,8 @@ int f3d_fuse_chunk_coded_dev(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int
 int f3d_debug_fastpath_audit(f3d_ctx* ctx, const void* xyz, f3d_dtype dtype, int64_t n,
                              const f3d_view* views, int nviews, int w, int h, uint64_t stats[4]);
 /* Diagnostic: how many points of the last fused call of this context the float32 kernel handed to the float64 middle
- * tier (counts[0]) and how many of those went on to the reference-arithmetic kernel (counts[1]).  Synchronises `stream`. */
+ * tier (counts[0]) and how many of those needed the reference's own arithmetic for at least one view (counts[1]).
+ * Synchronises `stream`. */
 int f3d_debug_fuse_deferred(f3d_ctx* ctx, void* stream, uint32_t counts[2]);
 /* Sort of the cloud by coarse grid cell: perm (int32 [n], caller-order index of sorted point i)
  * and, unless NULL, sorted_xyz (same dtype/size as xyz); device buffers owned by the caller. */
