@@ -334,6 +334,23 @@ def variants_leg(torch, ctx, dev, stream, xyz, dtype, n, views, V, S, flags, per
                                     labels_in_masks=int(len(np.unique(m5[:4].cpu().numpy()))), filter_classes=None,
                                     deferred_points=dict(to_float64_tier=d5[0], to_exact_arithmetic=d5[1]))
     del m5, v5
+    # what strong scaling can reach: the step of one rank's share of this cloud -- its first n/2, n/4, n/8 points against all
+    # the views -- without any exchange; the fixed work per launch and per call does not shrink with the share
+    m = torch.from_numpy(synth.masks(V, S, S, 'block64')).to(dev)
+    shares = {}
+    for parts in (2, 4, 8):
+        ns = n // parts
+
+        def fns():
+            ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, ns, views.data_ptr(), V, m.data_ptr(), S, S, 133, 0.5, None,
+                                        classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=None if perm_ptr is None else perm_ptr)
+        if perm_ptr is None:                                                   # (a prepared layout's permutation covers the whole cloud only)
+            tk = time_kernel(torch, fns, 10, stream)
+            shares[f'1/{parts}'] = dict(points=ns, ms_per_step=round(tk * 1e3, 4))
+    ctx.take_device_error(stream.cuda_stream)
+    if shares:
+        out['share_of_the_cloud_no_exchange'] = shares
+    del m
     return out
 
 
@@ -745,6 +762,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras and not (args.prepared or args.sorted or overlap):
         out['variants'] = variants_leg(torch, ctx, dev, stream, xyz, dtype, n, views, V, S, flags, perm_ptr)
+        if 'share_of_the_cloud_no_exchange' in out['variants']:
+            out['share_of_the_cloud_no_exchange'] = out['variants'].pop('share_of_the_cloud_no_exchange')
         out['c3_end_to_end'] = end_to_end_leg(torch, ctx, dev, stream, xyz, dtype, n, views, views_np, V, S, flt, flags, perm_ptr)
 
     if rank == 0 and world == 1 and not args.no_merge and not args.no_extras:
