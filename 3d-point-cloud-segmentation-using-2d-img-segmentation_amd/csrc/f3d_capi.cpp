@@ -106,7 +106,7 @@ size_t xyz_bytes(f3d_dtype dt, int64_t n) { return (size_t)n * 3 * (dt == F3D_F6
 
 int make_filter(f3d_ctx* ctx, const int32_t* filter, int nfilter, int ncols, bool cols_must_exist, hipStream_t s,
                 f3d_filter_args* fa) {
-    fa->nfilter = 0; fa->cls_dev = nullptr;
+    fa->nfilter = 0; fa->cls_dev = nullptr; fa->cls_host = nullptr;
     for (int k = 0; k < 8; ++k) fa->cls[k] = -1;
     if (nfilter < 0 || nfilter > F3D_MAX_FILTER) return fail(ctx, F3D_ERR_INVALID, "nfilter %d out of range", nfilter);
     if (nfilter == 0 || !filter) {
@@ -126,6 +126,7 @@ int make_filter(f3d_ctx* ctx, const int32_t* filter, int nfilter, int ncols, boo
     memcpy(ctx->filter_host, tmp, sizeof(int32_t) * nfilter);
     F3D_HIP(ctx, hipMemcpyAsync(ctx->filter_dev, ctx->filter_host, sizeof(int32_t) * nfilter, hipMemcpyHostToDevice, s));
     fa->cls_dev = ctx->filter_dev;
+    fa->cls_host = ctx->filter_host;
     return F3D_OK;
 }
 

@@ -26,6 +26,7 @@
 #pragma clang fp contract(off)
 
 #define F3D_BLOCK 256
+#define F3D_NO_PREFILL ((int64_t)0x7fffffffffffffffLL)   // "the label vector was not pre-filled": every label is stored
 #define F3D_PART_MAX_GROUPS 16            // view groups whose open-view masks a parked point carries (more: the point is redone from nothing)
 #ifndef F3D_MID_DENSE
 #define F3D_MID_DENSE 8                  // k_fuse_mid: more open views per point than this on a block's average -> the views run in the outer loop
@@ -521,7 +522,7 @@ template <bool WRITE_VOTES>
 __device__ __forceinline__ void finish_bin32(const uint32_t* hcol, int ncodes, const uint8_t* lut, const uint8_t* inv, int nfilter,
                                              const int* __restrict__ fcls, int nclasses, double threshold, bool store, int orig,
                                              int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad,
-                                             const uint16_t* cmin = nullptr) {
+                                             const uint16_t* cmin = nullptr, int64_t prefilled = F3D_NO_PREFILL) {
     const int ncols = nclasses + 1;
     const unsigned cbad = hcol[F3D_BLOCK];
     bad = cbad != 0u;
@@ -545,7 +546,7 @@ __device__ __forceinline__ void finish_bin32(const uint32_t* hcol, int ncodes, c
         win_c = (int)(best >> 8); win_i = (int)inv[best & 0xFFu];
     }
     const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold, cmin);
-    if (store) F3D_STORE_CLASS(&classes[orig], cls);
+    if (store && cls != prefilled) F3D_STORE_CLASS(&classes[orig], cls);      // (the label vector was filled with `prefilled` by a streaming kernel)
     if (WRITE_VOTES && store) {
         for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? hcol[b * F3D_BLOCK] : 0u); }
     }
@@ -575,7 +576,7 @@ template <bool WRITE_VOTES, bool WRAP>
 __device__ __forceinline__ bool finish_coded(unsigned nvalid, const uint32_t* hcol, int words, const uint8_t* lut, const uint8_t* inv,
                                              int nfilter, const int* __restrict__ fcls, int nclasses, double threshold, bool store,
                                              int orig, int64_t* __restrict__ classes, uint16_t* __restrict__ votes_out, bool& bad,
-                                             const uint16_t* cmin = nullptr) {
+                                             const uint16_t* cmin = nullptr, int64_t prefilled = F3D_NO_PREFILL) {
     const int ncols = nclasses + 1;
     unsigned best = 0, sum = 0;
     {
@@ -625,7 +626,7 @@ __device__ __forceinline__ bool finish_coded(unsigned nvalid, const uint32_t* hc
     }
     // total = the votes cast (every bin but "no sample"; a rejected label raises IndexError anyway)
     const int64_t cls = segment_point(win_c, win_i, (int)sum, nfilter, [&](int k) { return fcls[k]; }, nclasses, threshold, cmin);
-    if (store) F3D_STORE_CLASS(&classes[orig], cls);
+    if (store && cls != prefilled) F3D_STORE_CLASS(&classes[orig], cls);
     if (WRITE_VOTES && store) {                                                    // presence book: an absent label reads bin 0 = 0
         for (int l = 0; l < ncols; ++l) { const unsigned b = lut[l]; votes_out[(size_t)orig * ncols + l] = (uint16_t)(b >= 2u ? coded_count(hcol, b) : 0u); }
     }
@@ -746,7 +747,8 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                                                      const f3d_codebook* __restrict__ cb, int cmin, int cmax,
                                                      const float* __restrict__ ctabT, const double* __restrict__ vtabT,
                                                      uint32_t* __restrict__ carry, int chunk_flags, T* __restrict__ xyz_keep,
-                                                     unsigned long long* __restrict__ umask, uint32_t* __restrict__ park, int park_slots, int park_stride) {
+                                                     unsigned long long* __restrict__ umask, uint32_t* __restrict__ park, int park_slots, int park_stride,
+                                                     int64_t prefilled) {
     const int ncodes = cb->ncodes;                                        // wave-uniform: scalar load
     if (ncodes > cmax || ncodes < cmin) return;                           // the other instance's book
     const int words = (ncodes + 3) >> 2;
@@ -1133,9 +1135,9 @@ __global__ __launch_bounds__(F3D_BLOCK, F3D_FUSE_WAVES) void k_fuse(const T* __r
                 continue;
             }
             bool bad = false, trusted = true;
-            if (BIN32) finish_bin32<WRITE_VOTES>(hc, ncodes, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q], classes, votes_out, bad, vmin);
+            if (BIN32) finish_bin32<WRITE_VOTES>(hc, ncodes, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q], classes, votes_out, bad, vmin, prefilled);
             else trusted = finish_coded<WRITE_VOTES, WRAP>(nvalid[q], hc, words, lut, inv, nfilter, fcls, nclasses, threshold, live[q] & !defer[q], orig[q],
-                                                           classes, votes_out, bad, vmin);
+                                                           classes, votes_out, bad, vmin, prefilled);
             full = full | (live[q] & !trusted);
             const bool d = defer[q] | full;
             if (d) {
@@ -1624,6 +1626,23 @@ size_t f3d_fuse_todo_bytes(int64_t n, int nviews, int nclasses) {
     return 16 + (size_t)n * 8 + k * ((size_t)((nviews + 63) / 64) * 8 + (size_t)((nclasses + 1 + 2 + 3) >> 2) * 4);
 }
 
+// The label vector is filled with the label of a point nobody votes for ("unlabelled": nclasses, through the filter remap) by
+// streaming stores, and k_fuse scatters only the labels that differ.  A scattered 8-byte store is one write transaction on the fabric
+// whatever its size: 10M of them are ~350 us of the memory system's time (96-142 us of the step once overlapped with the view loops,
+// profiles/r03_summary.md); the fill is 80 MB at streaming speed.  At the reference's threshold 0.5 most points of a real scene and
+// 99.9 % of the synthetic one stay unlabelled; at threshold 0 the fill is 15 us spent for nothing.
+__global__ __launch_bounds__(F3D_BLOCK) void k_fill_labels(int64_t* __restrict__ classes, int64_t n, int64_t value) {
+    for (int64_t i = (int64_t)blockIdx.x * F3D_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * F3D_BLOCK)
+        __builtin_nontemporal_store(value, &classes[i]);
+}
+
+static int64_t unlabelled_after_remap(int nclasses, const f3d_filter_args& flt) {   // segment_point's answer for a point without votes
+    int64_t r = nclasses;
+    if (flt.nfilter > 0 && !flt.cls_host) return F3D_NO_PREFILL;               // (no host copy of the list: store every label)
+    for (int k = 0; k < flt.nfilter; ++k) if (r == k) r = flt.cls_host[k];
+    return r;
+}
+
 template <typename KernelT>
 static hipError_t raise_lds(KernelT kernel, size_t lds) {
     if (lds <= 48 * 1024) return hipSuccess;
@@ -1655,6 +1674,12 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
     const size_t lds_exact = f3d_fuse_lds_bytes(mode, nclasses);
     if (lds_exact > 160 * 1024 || lds_full > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e;
+    int64_t prefilled = F3D_NO_PREFILL;
+    if (fast && !(chunk_flags & 2)) {                        // (a chunk that parks its bins writes no labels)
+        prefilled = unlabelled_after_remap(nclasses, flt);
+        if (prefilled != F3D_NO_PREFILL)
+            hipLaunchKernelGGL(k_fill_labels, dim3(grid_for(n, F3D_BLOCK, 2048)), dim3(F3D_BLOCK), 0, s, classes, n, prefilled);
+    }
     if (fast) {
         // the guarded vote: an 8-bit bin of a real code can wrap (more than 255 views), or the "no sample" byte could (a point casts up to
         // nviews + 3 ngroups + 2 votes, placeholders included: from ~240 views on)
@@ -1677,19 +1702,19 @@ static hipError_t launch_fuse_t(const void* xyz, int64_t n, const f3d_view* view
         // knows how many labels the masks contain -- the code book says which instance runs, the others return at once
         const size_t lds_mid = fuse_lds_bytes(F3D_PACKED_SMALL_WORDS, 2, one_group);
         hipLaunchKernelGGL(ks, g, b, lds_small, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
-                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
+                           classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 0, F3D_BIN32_MAX_CODES, ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride, prefilled);
         if (nclasses + 3 > F3D_BIN32_MAX_CODES)
             hipLaunchKernelGGL(km2, g, b, lds_mid, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
                                classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, F3D_BIN32_MAX_CODES + 1, 4 * F3D_PACKED_SMALL_WORDS,
-                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride, prefilled);
         if (nclasses + 3 > 4 * F3D_PACKED_SMALL_WORDS)
             hipLaunchKernelGGL(km3, g, b, lds_large, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev, threshold,
                                classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_SMALL_WORDS + 1, 4 * F3D_PACKED_LARGE_WORDS,
-                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride, prefilled);
         if (nclasses + 3 > 4 * F3D_PACKED_LARGE_WORDS) {
             hipLaunchKernelGGL(kf, g, b, lds_full, s, (const T*)xyz, n, cviews, cnv, ccm, h, w, nclasses, flt.nfilter, flt.cls_dev,
                                threshold, classes, votes, err, perm, gather_xyz ? 1 : 0, todo_count, todo, cb, 4 * F3D_PACKED_LARGE_WORDS + 1, 256,
-                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride);
+                               ctabT, vtabT, carry, chunk_flags, (T*)xyz_keep, umask, park, park_slots, park_stride, prefilled);
         }
         if (chunk_flags & 2) return hipGetLastError();       // more view chunks to come
         // float64 tier on the deferred points' open views, the reference's arithmetic for what it cannot prove either.  Beyond 255 views a
@@ -1731,7 +1756,7 @@ hipError_t f3d_launch_fuse_setup(const f3d_view* views_dev, int v0, int v1, void
     if (cnv <= 0) return hipSuccess;
     float* ctabT = reinterpret_cast<float*>(tables);
     double* vtabT = reinterpret_cast<double*>(reinterpret_cast<char*>(tables) + (size_t)((cnv + 63) / 64) * 64 * 24 * sizeof(float));
-    f3d_filter_args none; none.nfilter = 0; none.cls_dev = nullptr; for (int k = 0; k < 8; ++k) none.cls[k] = -1;
+    f3d_filter_args none; none.nfilter = 0; none.cls_dev = nullptr; none.cls_host = nullptr; for (int k = 0; k < 8; ++k) none.cls[k] = -1;
     if (book_flt && (book_nclasses < 0 || book_nclasses > F3D_CODE_MAX_NCLASSES)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_fuse_setup, dim3(book_flt ? 9 : 8), dim3(F3D_BLOCK), 0, s, views_dev + v0, cnv, ctabT, vtabT, cb, threshold, todo_count,
                        book_nclasses, book_flt ? pick_book(*book_flt, book_want_votes) : -1, book_flt ? *book_flt : none);

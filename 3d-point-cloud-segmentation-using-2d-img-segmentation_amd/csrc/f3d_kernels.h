@@ -40,6 +40,7 @@ struct f3d_filter_args {                   // filter_classes of VotingSegmentati
     int nfilter;                           // 0 = no filter
     int cls[8];                            // the list itself when nfilter <= 8 (unused slots = -1)
     const int* cls_dev;                    // device copy of the list when nfilter > 8
+    const int* cls_host;                   // host copy of the whole list (the context's staging array; NULL when nfilter == 0)
 };
 
 // device-resident code book of the fused path's vote bins (built per call by k_mask_presence + k_code_lut, f3d_fuse.hip)
