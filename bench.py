@@ -64,6 +64,9 @@ def parse():
     return ap.parse_args()
 
 
+THRESHOLD = float(os.environ.get('F3D_BENCH_THRESHOLD', '0.5'))      # (experiments only: the headline is BASELINE's 0.5)
+
+
 def fuse_instance(labels_present, flt):
     """Which k_fuse instance the code book selects (csrc/f3d_fuse.hip: launch_fuse_t): codes = labels + 2 (no sample, rejected)."""
     codes = (3 + len(set(flt))) if (flt and len(flt) <= 8) else labels_present + 2
@@ -513,7 +516,7 @@ def main():
         m = masks_full if masks_t is None else masks_t
         if not overlap:
             ctx.project_vote_argmax_dev(xyz.data_ptr(), dtype, n, views.data_ptr(), V, m.data_ptr(), S, S,
-                                        133, 0.5, flt, classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
+                                        133, THRESHOLD, flt, classes.data_ptr(), None, stream.cuda_stream, flags=flags, perm_ptr=perm_ptr)
             return
         i = fuse_no[0]
         issue_sort(i)
