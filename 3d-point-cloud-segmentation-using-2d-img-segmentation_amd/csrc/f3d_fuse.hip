@@ -34,7 +34,13 @@
 #ifndef F3D_NT_CLASSES
 #define F3D_NT_CLASSES 1                 // the (scattered) label stores carry the non-temporal hint (measured: -2.5 % of the step)
 #endif
-#if F3D_NT_CLASSES
+#if defined(F3D_EXP_STORE) && F3D_EXP_STORE == 2          // timing experiments (results wrong): no label store at all
+#define F3D_STORE_CLASS(p, v) ((void)(v))
+#elif defined(F3D_EXP_STORE) && F3D_EXP_STORE == 3        // ... a one-byte label at the same (scattered) index
+#define F3D_STORE_CLASS(p, v) (reinterpret_cast<uint8_t*>(classes)[(p) - classes] = (uint8_t)(v))
+#elif defined(F3D_EXP_STORE) && F3D_EXP_STORE == 4        // ... one byte, non-temporal
+#define F3D_STORE_CLASS(p, v) __builtin_nontemporal_store((uint8_t)(v), reinterpret_cast<uint8_t*>(classes) + ((p) - classes))
+#elif F3D_NT_CLASSES
 #define F3D_STORE_CLASS(p, v) __builtin_nontemporal_store((int64_t)(v), (p))
 #else
 #define F3D_STORE_CLASS(p, v) (*(p) = (v))
